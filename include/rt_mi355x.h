@@ -1,0 +1,204 @@
+/*
+ * rt_mi355x.h -- C ABI of librt_mi355x.so, the MI355X (gfx950) path tracer that
+ * replaces the per-pixel sampling loop of aiifabbf/ray-tracer.
+ *
+ * The reference has no FFI or plugin interface; its de-facto operator API is the
+ * trait/builder surface used by the example drivers.
+ * Crossing a C boundary once per ray (render::color, src/render.rs:5) would erase
+ * any GPU gain, so the boundary sits one level up: the scene is described through
+ * calls that mirror the reference constructors one-to-one, committed once
+ * (flattened into SoA device arrays + BVH), and rendered per image / per tile set.
+ * Each entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain C types only: pointers, sizes, doubles, ints.  No torch / HIP types.
+ *   - status returns: 0 = ok, negative = error; rt_last_error() gives the text
+ *     (thread-local).  Constructors return an id >= 0 or a negative error.
+ *     The reference signals "nothing" with Option and its drivers unwrap()/panic
+ *     (examples/book-one.rs:32); here nothing aborts across the boundary.
+ *   - ids returned by rt_add_* stay valid until rt_scene_destroy; sharing an id
+ *     between sprites is the reference's Arc::clone
+ *     (examples/cornell-box.rs:62,70,78,96,118).
+ *   - matrices: 16 doubles, column-major like src/mat4.rs:5-17 (m[12..14] =
+ *     translation).  NULL = identity.
+ *   - images: linear radiance, double, layout [y][x][3] with y UP (row 0 is the
+ *     bottom row) exactly like `buffer[y][x]` in examples/book-one.rs:53,87.
+ *   - all arithmetic on the path is IEEE binary64 like the reference.
+ *   - the scene is immutable after rt_scene_commit; rt_render* may be called
+ *     concurrently on a committed scene (the traits are Send + Sync upstream,
+ *     src/ray.rs:85).
+ */
+#ifndef RT_MI355X_H
+#define RT_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_ERR_INVALID (-1)     /* bad argument / id */
+#define RT_ERR_EMPTY (-2)       /* BoundingVolumeHierarchyNode::new(vec![]) -> None (src/optimize.rs:367-370) */
+#define RT_ERR_DEVICE (-3)      /* HIP failure or no GPU */
+#define RT_ERR_UNSUPPORTED (-4) /* scene feature outside the closed enums */
+#define RT_ERR_STATE (-5)       /* call order (e.g. render before commit) */
+
+typedef struct rt_scene rt_scene;
+
+const char *rt_last_error(void);
+const char *rt_version(void);
+/* number of visible HIP devices; 0 when there is none (never an error) */
+int rt_device_count(void);
+
+/* ---- Mat4 helpers: src/mat4.rs:21-28,36-47,52-80,85-143,146-181,184-243 ---- */
+void rt_mat4_identity(double out[16]);
+void rt_mat4_translation(const double offset[3], double out[16]);
+void rt_mat4_rotation(double radians, const double axis[3], double out[16]);
+void rt_mat4_multiplied(const double self[16], const double other[16], double out[16]); /* self * other */
+double rt_mat4_determinant(const double m[16]);
+int rt_mat4_inversed(const double m[16], double out[16]); /* RT_ERR_INVALID iff det == 0.0 */
+
+/* ---- scene lifetime ---- */
+rt_scene *rt_scene_create(void);
+void rt_scene_destroy(rt_scene *);
+
+/* ---- textures: SolidColor::new / CheckerTexture::new / ImageTexture::new
+ *      (src/material.rs:200-215,217-245,247-265).  ImageTexture's closure cannot
+ *      cross the boundary; the one closure the reference uses -- nearest texel of
+ *      an RGB8 image, examples/main.rs:267-280 -- is the supported form. ---- */
+int rt_add_texture_solid(rt_scene *, const double rgb[3]);
+int rt_add_texture_checker(rt_scene *, int black_texture, int white_texture);
+int rt_add_texture_image_rgb8(rt_scene *, const uint8_t *rgb, int width, int height);
+
+/* ---- materials: Lambertian::new, Metal::new, Dielectric::new, DiffuseLight::new,
+ *      Isotropic::new (src/material.rs:36-46,81-97,128-138,279-288,307-315) ---- */
+int rt_add_material_lambertian(rt_scene *, int albedo_texture);
+int rt_add_material_metal(rt_scene *, int albedo_texture, double fuzziness);
+int rt_add_material_dielectric(rt_scene *, double refractive);
+int rt_add_material_diffuse_light(rt_scene *, int emission_texture);
+int rt_add_material_isotropic(rt_scene *, int albedo_texture);
+
+/* ---- geometries: Sphere::new (src/geometry.rs:17-19), Rectangle::new (:139-144),
+ *      BoundingVolumeHierarchyNode::new(Cube::new(w,h,d)) (src/geometry.rs:254-286 as
+ *      wrapped by examples/cornell-box.rs:85-101), ConstantMedium::new(boundary, density)
+ *      (src/volume.rs:25-30; boundary must be a sphere geometry) ---- */
+int rt_add_geometry_sphere(rt_scene *, double radius);
+int rt_add_geometry_rectangle(rt_scene *, double width, double height);
+int rt_add_geometry_cube(rt_scene *, double width, double height, double depth);
+int rt_add_geometry_constant_medium(rt_scene *, int boundary_geometry, double density);
+
+/* ---- Sprite::builder().geometry(g).material(m).transform(M).build()
+ *      (src/sprite.rs:22-72).  geometry / material = -1 is the reference's None:
+ *      such a sprite is never hit / shades black (src/sprite.rs:95,136; src/render.rs:18-20).
+ *      A singular M makes the sprite unhittable (src/sprite.rs:131-134). ---- */
+int rt_add_sprite(rt_scene *, int geometry, int material, const double transform[16]);
+
+/* ---- world = BoundingVolumeHierarchyNode::new(all sprites).unwrap()
+ *      (src/optimize.rs:366-440, examples/book-one.rs:32).  Nested
+ *      BoundingVolumeHierarchyNode children without a transform
+ *      (examples/main.rs:191,303) are the same flat set of sprites: the reference's
+ *      traversal is unpruned and order-free (src/optimize.rs:469-498), so the
+ *      nearest hit does not depend on the tree.  Flattens the scene, builds the
+ *      acceleration structure and, when device >= 0, uploads it to that HIP device.
+ *      device = -1 keeps it host-only (inspection / CPU-side tests).
+ *      RT_ERR_EMPTY for an empty scene. ---- */
+int rt_scene_commit(rt_scene *, int device);
+
+/* ---- PerspectiveCamera::new(eye, center, up, fov, aspect, focusDistance, lensRadius)
+ *      (src/camera.rs:25-59); fov in radians.  Keeps the reference's un-normalised
+ *      `u` (Q1) and scalar lens offset (Q2). ---- */
+typedef struct rt_camera {
+    double eye[3];
+    double lower_left[3];
+    double horizontal[3];
+    double vertical[3];
+    double lens_radius;
+} rt_camera;
+int rt_camera_perspective(rt_camera *out, const double eye[3], const double center[3], const double up[3], double fov,
+                          double aspect, double focus_distance, double lens_radius);
+
+/* ---- the hot path: the per-pixel sampling loop of the drivers
+ *      (examples/book-one.rs:56-88 = cornell-box.rs:159-189 = main.rs:71-101):
+ *      for every pixel, spp times: jitter, camera.ray, color(ray, world, max_depth),
+ *      accumulate, divide by spp.  Sample stream id = (y*W + x)*spp + s under
+ *      `seed` (include/rt_rng.h). ---- */
+typedef struct rt_render_params {
+    int width, height;
+    int spp;
+    int max_depth; /* the literal 100 in the drivers (examples/book-one.rs:74) */
+    uint64_t seed;
+    /* tile sharding: the image is cut into 8x8 pixel
+     * tiles, tile id = ty * tiles_x + tx; this call renders the tiles with
+     * id % shard_count == shard_index.  {0, 1} renders the whole image. */
+    int shard_index, shard_count;
+    unsigned flags; /* RT_FLAG_* */
+} rt_render_params;
+
+#define RT_TILE 8                 /* tile edge in pixels */
+#define RT_FLAG_COUNTERS 1u       /* also accumulate rt_counters (slower build of the kernel) */
+
+typedef struct rt_counters {
+    uint64_t samples, segments, nodes_visited, prims_tested, rng_draws, wave_iterations, lane_iterations;
+} rt_counters;
+
+/* Render into host memory: out_rgb[(y*W + x)*3 + c].  With shard_count > 1 only
+ * this shard's pixels are written.  counters may be NULL. */
+int rt_render(rt_scene *, const rt_camera *, const rt_render_params *, double *out_rgb, rt_counters *counters);
+
+/* Device-resident variant for callers that own device memory and a stream
+ * (plumbed as raw pointers; `stream` is a hipStream_t or NULL).
+ * d_tiles_out receives this shard's tiles PACKED in ascending tile id:
+ * [k][py][px][3] doubles, k-th owned tile, RT_TILE*RT_TILE pixels each.
+ * Asynchronous: returns after enqueueing.  rt_shard_tile_count gives the number
+ * of tiles (buffer size = count * 64 * 3 doubles). */
+int rt_shard_tile_count(int width, int height, int shard_index, int shard_count);
+int rt_render_tiles_device(rt_scene *, const rt_camera *, const rt_render_params *, void *d_tiles_out, void *d_counters,
+                           void *stream);
+/* Un-permute gathered shards into a row-major image on the device:
+ * d_gathered = shard_count buffers of `tiles_per_shard_padded` tiles each,
+ * back to back (what one RCCL gather of equal-sized chunks produces). */
+int rt_unpack_tiles_device(const void *d_gathered, int tiles_per_shard_padded, int shard_count, int width, int height,
+                           void *d_image_out, void *stream);
+/* time (ms) the last rt_render / rt_render_tiles_device kernel took on its stream,
+ * measured with HIP events recorded around the launch; blocks until it finished */
+int rt_last_kernel_ms(rt_scene *, float *ms);
+
+/* ---- output: tone map + P3 text of the drivers (examples/book-one.rs:28-30,90-100):
+ *      gamma 2, clamp high, truncate, NaN / negative -> 255 (Q13); rows top-down ---- */
+void rt_tonemap_rgb8(const double *rgb, size_t n_pixels, uint8_t *out_rgb8);
+int rt_write_ppm_p3(const char *path, const double *rgb, int width, int height);
+
+/* ---- inspection of the committed flat scene (tests, algorithmic-byte accounting) ---- */
+typedef struct rt_scene_info {
+    int n_prims;        /* leaves of the acceleration structure */
+    int n_child_prims;  /* faces inside cube instances */
+    int n_nodes;
+    int max_depth;      /* deepest leaf */
+    int n_materials, n_textures, n_xforms;
+    int node_bytes, prim_bytes, material_bytes; /* bytes one traversal step / test reads */
+    unsigned feature_mask;                      /* RT_FEAT_* present in the scene */
+    size_t device_bytes;                        /* total resident bytes after upload */
+} rt_scene_info;
+int rt_scene_get_info(const rt_scene *, rt_scene_info *out);
+/* copy of the flat BVH: nodes as 16 doubles each {lo0[3],hi0[3],lo1[3],hi1[3],child0,child1,-,-};
+ * child >= 0 inner node index, child < 0 leaf ~prim */
+int rt_scene_copy_nodes(const rt_scene *, double *out, int max_nodes);
+/* world-space AABB of prim i: {lo[3], hi[3]} */
+int rt_scene_prim_bounds(const rt_scene *, int prim, double out[6]);
+
+/* ---- device self-test used by the GPU parity tests: evaluates sqrt, div on the
+ *      device for n inputs so the host can check they are correctly rounded ---- */
+int rt_probe_device_math(int device, const double *a, const double *b, int n, double *out_sqrt_a, double *out_a_div_b);
+
+#define RT_FEAT_SPHERE_T 1u   /* translation-only sphere sprites */
+#define RT_FEAT_GENERAL 2u    /* sprites with a general matrix / rectangles / cubes */
+#define RT_FEAT_MEDIUM 4u     /* ConstantMedium */
+#define RT_FEAT_TEXTURED 8u   /* checker / image textures (uv needed) */
+#define RT_FEAT_LENS 16u
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_MI355X_H */

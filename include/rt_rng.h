@@ -1,0 +1,145 @@
+/*
+ * rt_rng.h -- the ONE definition of the injected random-number contract.
+ *
+ * Shared verbatim by the CPU oracle (oracle/), the host scene builders and the
+ * HIP kernels (ray-tracer_amd/csrc).  Nothing else in the build may define a
+ * generator of its own.
+ *
+ * Why it exists: the reference draws every random number from the `rand` crate's
+ * OS-seeded, unseedable `thread_rng()` (reference src/util.rs:2-4,10,28-34,
+ * src/material.rs:6-7,164, src/volume.rs:58-60,80-82, examples/book-one.rs:70-72)
+ * with `rand = "*"` and no lockfile (Cargo.toml:9-13), so the reference can never
+ * reproduce its own image.  "Identical RNG seeds" therefore means: oracle and
+ * kernel consume THIS generator, in the program order documented below.
+ *
+ * Generator: SplitMix64 (Steele, Lea, Flood 2014) used in counter mode.
+ *   draw n (n >= 1) of stream `stream` under `seed`:
+ *       x_n = mix64( base + n * GAMMA ),   base = mix64(seed) + (stream << 24) * GAMMA
+ *   For a fixed seed the map (stream, n) -> state is a bijection, so no two
+ *   samples ever share a sub-sequence.  A stream may draw < 2^23 sequential
+ *   numbers; counters >= 2^23 are the "keyed" domain used by ConstantMedium.
+ *
+ * Float conversions restate rand 0.7.x (the newest series that still has the
+ * two-argument `gen_range(low, high)` the reference calls):
+ *   random::<f64>()         -> (x >> 11) * 2^-53                 [Standard, 53 bit]
+ *   gen_range(lo, hi)       -> v12 * (hi-lo) + (lo - (hi-lo)),   v12 = 1.mantissa(x >> 12)
+ *                              retried while the result is >= hi  [UniformFloat::sample_single]
+ *
+ * Stream id of a sample: pixel_index * spp + s, pixel_index = y * W + x (y up).
+ * Draw order inside a sample (SURVEY.md section 8(a) "RNG order"):
+ *   U1 (x jitter), U2 (y jitter)                    examples/book-one.rs:71-72
+ *   lens disk trials, 2 draws each, if lens != 0    src/util.rs:30-41
+ *   per segment: the hit material's draws           src/material.rs:61-69,99-118,147-192,318-325
+ *     Lambertian / Isotropic / fuzzy Metal: ball trials, 3 draws each (src/util.rs:6-15)
+ *     Dielectric: 1 draw iff refraction is possible
+ * ConstantMedium free-flight draws are NOT taken from the sequential counter
+ * (in the reference they depend on the random tree's visiting order,
+ * src/volume.rs:58-63 + src/optimize.rs:473-488, i.e. they are unpinned); they
+ * are keyed by (stream, segment index, medium slot) -> rt_rng_keyed().
+ */
+#ifndef RT_RNG_H
+#define RT_RNG_H
+
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define RT_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define RT_HD static inline
+#endif
+
+#define RT_RNG_GAMMA 0x9E3779B97F4A7C15ull
+#define RT_RNG_STREAM_SHIFT 24
+#define RT_RNG_KEYED_BASE (1ull << 23)
+/* stream id reserved for host-side scene construction (never a sample id) */
+#define RT_RNG_SCENE_STREAM ((1ull << 40) - 1ull)
+
+typedef struct rt_rng {
+    uint64_t base; /* mix64(seed) + (stream << 24) * GAMMA */
+    uint64_t s;    /* base + n * GAMMA after n sequential draws */
+} rt_rng;
+
+RT_HD uint64_t rt_mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+RT_HD uint64_t rt_rng_base(uint64_t seed, uint64_t stream) {
+    return rt_mix64(seed) + (stream << RT_RNG_STREAM_SHIFT) * RT_RNG_GAMMA;
+}
+
+RT_HD void rt_rng_init(rt_rng *g, uint64_t seed, uint64_t stream) {
+    g->base = rt_rng_base(seed, stream);
+    g->s = g->base;
+}
+
+/* next sequential 64-bit draw */
+RT_HD uint64_t rt_rng_next(rt_rng *g) {
+    g->s += RT_RNG_GAMMA;
+    return rt_mix64(g->s);
+}
+
+/* keyed draw: independent of how many sequential draws were made */
+RT_HD uint64_t rt_rng_keyed_from_base(uint64_t base, uint32_t segment, uint32_t slot) {
+    uint64_t n = RT_RNG_KEYED_BASE + ((uint64_t)(segment & 0xFFFu) << 10) + (uint64_t)(slot & 0x3FFu);
+    return rt_mix64(base + n * RT_RNG_GAMMA);
+}
+
+RT_HD double rt_bits_to_double(uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __longlong_as_double((long long)b);
+#else
+    double d;
+    memcpy(&d, &b, sizeof d);
+    return d;
+#endif
+}
+
+/* rand 0.7 Standard for f64: 53 random bits, [0,1) */
+RT_HD double rt_u64_to_unit53(uint64_t x) {
+    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+
+/* 1.mantissa in [1,2), 52 random bits (rand 0.7 into_float_with_exponent(0)) */
+RT_HD double rt_u64_to_v12(uint64_t x) {
+    return rt_bits_to_double((x >> 12) | 0x3FF0000000000000ull);
+}
+
+/* gen_range(0.0, 1.0): scale = 1, offset = -1; always < 1 */
+RT_HD double rt_u64_to_range01(uint64_t x) {
+    return rt_u64_to_v12(x) - 1.0;
+}
+
+/* gen_range(-1.0, 1.0): scale = 2, offset = -3; exact, always < 1 */
+RT_HD double rt_u64_to_range11(uint64_t x) {
+    return rt_u64_to_v12(x) * 2.0 - 3.0;
+}
+
+RT_HD double rt_rng_unit53(rt_rng *g) { return rt_u64_to_unit53(rt_rng_next(g)); }
+RT_HD double rt_rng_range01(rt_rng *g) { return rt_u64_to_range01(rt_rng_next(g)); }
+RT_HD double rt_rng_range11(rt_rng *g) { return rt_u64_to_range11(rt_rng_next(g)); }
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+/* general gen_range(low, high) with the rejection step of
+ * UniformFloat::sample_single (host-side scene construction only) */
+static inline double rt_rng_gen_range(rt_rng *g, double low, double high) {
+    double scale = high - low;
+    double offset = low - scale;
+    for (;;) {
+        double v12 = rt_u64_to_v12(rt_rng_next(g));
+        volatile double prod = v12 * scale; /* no fused multiply-add */
+        double res = prod + offset;
+        if (res < high) return res;
+    }
+}
+/* gen_range(0, 3) on integers (BVH split axis, src/optimize.rs:374-375): the
+ * oracle only needs *a* seeded axis stream; widening multiply, top bits. */
+static inline uint32_t rt_rng_gen_below(rt_rng *g, uint32_t n) {
+    uint64_t x = rt_rng_next(g) >> 32;
+    return (uint32_t)((x * (uint64_t)n) >> 32);
+}
+#endif
+
+#endif /* RT_RNG_H */

@@ -1,0 +1,130 @@
+/*
+ * rt_oracle.h -- C API of the CPU oracle.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under ray-tracer_amd/ may include, link or
+ * call this.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg use it, as the checker -- never as the thing measured or shipped.
+ *
+ * The oracle is a plain C++17, all-f64 restatement of the reference's hot path
+ * (aiifabbf/ray-tracer: src/render.rs, src/ray.rs, src/optimize.rs,
+ * src/geometry.rs, src/sprite.rs, src/volume.rs, src/material.rs, src/util.rs,
+ * src/camera.rs, src/vec3.rs, src/vec4.rs, src/mat4.rs and the example
+ * drivers), quirks Q1-Q14 of SURVEY.md section 8 included, with the injected
+ * generator of include/rt_rng.h in place of the unseedable `thread_rng()`.
+ *
+ * PARITY STATUS: the Rust reference cannot be built in this image (no rustc /
+ * cargo, no network) and its own tests hold no golden vectors (the single test,
+ * src/mat4.rs:398-408, only prints).  The oracle is pinned by hand-derived
+ * known-answer tests taken straight from the cited formulas
+ * (tests/test_oracle_kat.py); against the real Rust
+ * binary parity is statistical only ("parity unpinned" in the sense of the
+ * task statement -- see DESIGN.md).
+ */
+#ifndef RT_ORACLE_H
+#define RT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_scene orc_scene;
+
+orc_scene *orc_scene_new(void);
+void orc_scene_free(orc_scene *);
+
+/* textures (src/material.rs:196-271) -> texture id */
+int orc_tex_solid(orc_scene *, double r, double g, double b);
+int orc_tex_checker(orc_scene *, int black, int white);
+int orc_tex_image_rgb8(orc_scene *, const uint8_t *rgb, int w, int h);
+
+/* materials (src/material.rs:24-193,274-326) -> material id */
+int orc_mat_lambertian(orc_scene *, int albedo_tex);
+int orc_mat_metal(orc_scene *, int albedo_tex, double fuzziness);
+int orc_mat_dielectric(orc_scene *, double refractive);
+int orc_mat_diffuse_light(orc_scene *, int emission_tex);
+int orc_mat_isotropic(orc_scene *, int albedo_tex);
+
+/* geometries (src/geometry.rs, src/volume.rs) -> geometry id.
+ * cube = BoundingVolumeHierarchyNode::new(Cube::new(w,h,d)) as the examples
+ * wrap it (examples/cornell-box.rs:85-101); bvh_seed seeds its random axes. */
+int orc_geom_sphere(orc_scene *, double radius);
+int orc_geom_rectangle(orc_scene *, double w, double h);
+int orc_geom_cube_bvh(orc_scene *, double w, double h, double d, uint64_t bvh_seed);
+int orc_geom_constant_medium(orc_scene *, int boundary_geom, double density);
+
+/* Sprite::builder().geometry().material().transform().build() (src/sprite.rs:22-72)
+ * -> object id.  geometry / material = -1 for None; M = 16 doubles column-major
+ * (src/mat4.rs:5-7) or NULL for identity. */
+int orc_sprite(orc_scene *, int geometry, int material, const double *M);
+/* BoundingVolumeHierarchyNode::new(objects) used as a child object (examples/main.rs:191,303) */
+int orc_object_bvh(orc_scene *, const int *objects, int n, uint64_t bvh_seed);
+
+/* world = BoundingVolumeHierarchyNode::new(objects).unwrap()  (src/optimize.rs:366)
+ * returns 0, or -1 when the reference would return None (empty input) */
+int orc_world_bvh(orc_scene *, const int *objects, int n, uint64_t bvh_seed);
+/* world = Vec<Arc<dyn Hit>> linear scan (src/geometry.rs:76-116) */
+int orc_world_list(orc_scene *, const int *objects, int n);
+
+/* PerspectiveCamera::new (src/camera.rs:25-59); fov in radians */
+void orc_camera_perspective(orc_scene *, const double eye[3], const double center[3], const double up[3],
+                            double fov, double aspect, double focus_distance, double lens_radius);
+
+typedef struct orc_counters {
+    uint64_t samples, segments, aabb_tests, prim_tests, rng_draws;
+} orc_counters;
+
+#define ORC_FLAG_ITERATIVE 1u /* L = sum_k (prod_{j<k} att_j) * e_k instead of the nested recursion */
+
+/* The per-pixel sampling loop of the example drivers (examples/book-one.rs:56-88).
+ * Renders pixels x in [x0,x1), y in [y0,y1) (y up) of a W x H image into
+ * out[(y*W + x)*3 + c] (linear radiance, already divided by spp; untouched
+ * elsewhere).  nthreads rows are dealt y % nthreads == i like the reference.
+ * counters may be NULL. */
+int orc_render(orc_scene *, int W, int H, int spp, int max_depth, uint64_t seed, int x0, int y0, int x1, int y1,
+               unsigned flags, int nthreads, double *out, orc_counters *counters);
+
+/* per-sample radiance of one pixel: out[s*3 + c], s in [0, spp) */
+int orc_render_pixel_samples(orc_scene *, int W, int H, int spp, int max_depth, uint64_t seed, int x, int y,
+                             unsigned flags, double *out);
+
+/* tone map + P3 text of examples/book-one.rs:28-30,90-100; rgb is [y][x][3], y up */
+int orc_write_ppm_p3(const char *path, const double *rgb, int W, int H);
+void orc_tonemap_rgb8(const double *rgb, int n_pixels, uint8_t *out);
+
+/* ---- known-answer-test probes (one per reference function) ---- */
+/* Sphere::hit (src/geometry.rs:43-73): returns 1 on hit; out = t, p[3], n[3], u, v */
+int orc_kat_sphere_hit(double radius, const double o[3], const double d[3], double out[9]);
+int orc_kat_rectangle_hit(double w, double h, const double o[3], const double d[3], double out[9]);
+/* AxisAlignedBoundingBox::hit (src/optimize.rs:61-82) */
+int orc_kat_aabb_hit(const double mn[3], const double mx[3], const double o[3], const double d[3]);
+void orc_kat_reflect(const double v[3], const double n[3], double out[3]);
+int orc_kat_refract(const double v[3], const double n[3], double ratio, double out[3]);
+double orc_kat_schlick(double theta, double n1, double n2);
+void orc_kat_mat4_translation(const double t[3], double out[16]);
+void orc_kat_mat4_rotation(double radians, const double axis[3], double out[16]);
+void orc_kat_mat4_multiplied(const double a[16], const double b[16], double out[16]);
+double orc_kat_mat4_determinant(const double a[16]);
+int orc_kat_mat4_inversed(const double a[16], double out[16]);
+void orc_kat_vec4_transformed(const double v[4], const double m[16], double out[4]);
+/* camera internals: out = lowerLeft[3], horizontal[3], vertical[3] */
+void orc_kat_camera_frame(orc_scene *, double out[9]);
+/* camera.ray(u, v) with the sample's generator: out = origin[3], direction[3] */
+void orc_kat_camera_ray(orc_scene *, double u, double v, uint64_t seed, uint64_t stream, double out[6]);
+/* world.hit(ray): 1 on hit; out = t, p[3], n[3], u, v, material id (as double, -1 none) */
+int orc_kat_world_hit(orc_scene *, const double o[3], const double d[3], uint64_t seed, uint64_t stream, double out[10]);
+/* number of BVH nodes of the world tree (src/optimize.rs:366-440), nested object BVHs not counted */
+int orc_kat_world_node_count(orc_scene *);
+/* first n sequential draws of (seed, stream) as raw u64 */
+void orc_kat_rng_u64(uint64_t seed, uint64_t stream, int n, uint64_t *out);
+/* randomInUnitSphere / randomInUnitDisk (src/util.rs:6-15,27-42) */
+void orc_kat_random_in_unit_sphere(uint64_t seed, uint64_t stream, double out[3]);
+void orc_kat_random_in_unit_disk(uint64_t seed, uint64_t stream, double out[3]);
+/* texture.value(uv, p) */
+void orc_kat_texture_value(orc_scene *, int tex, double u, double v, double out[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

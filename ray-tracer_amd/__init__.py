@@ -1,0 +1,334 @@
+"""ray-tracer_amd -- harness glue (ctypes + numpy) around librt_mi355x.so.
+
+The product is the C-ABI shared library built from ``csrc/`` (hand-written HIP
+kernels for gfx950 + host flattener); this package only loads it and mirrors the
+reference's builder vocabulary (Sprite / Sphere / Lambertian / PerspectiveCamera,
+reference src/sprite.rs:22-72, src/geometry.rs, src/material.rs, src/camera.rs:25-33)
+so that tests and bench.py read like the reference's example drivers.
+
+There is no Python or CPU rendering path: if the library is missing, or no HIP
+device is present, rendering raises.
+
+The directory name contains a hyphen, so load it with ``importlib`` (see
+``load_package`` in ``__graft_entry__.py``) under the module name ``ray_tracer_amd``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "lib" / "librt_mi355x.so"
+
+RT_TILE = 8
+RT_FLAG_COUNTERS = 1
+RT_FEAT_SPHERE_T, RT_FEAT_GENERAL, RT_FEAT_MEDIUM, RT_FEAT_TEXTURED, RT_FEAT_LENS = 1, 2, 4, 8, 16
+
+
+class RtError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"librt_mi355x error {code}: {msg}")
+        self.code = code
+
+
+class rt_camera(C.Structure):
+    _fields_ = [("eye", C.c_double * 3), ("lower_left", C.c_double * 3), ("horizontal", C.c_double * 3),
+                ("vertical", C.c_double * 3), ("lens_radius", C.c_double)]
+
+
+class rt_render_params(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("spp", C.c_int), ("max_depth", C.c_int),
+                ("seed", C.c_uint64), ("shard_index", C.c_int), ("shard_count", C.c_int), ("flags", C.c_uint)]
+
+
+class rt_counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("samples", "segments", "nodes_visited", "prims_tested", "rng_draws",
+                                            "wave_iterations", "lane_iterations")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class rt_scene_info(C.Structure):
+    _fields_ = [("n_prims", C.c_int), ("n_child_prims", C.c_int), ("n_nodes", C.c_int), ("max_depth", C.c_int),
+                ("n_materials", C.c_int), ("n_textures", C.c_int), ("n_xforms", C.c_int), ("node_bytes", C.c_int),
+                ("prim_bytes", C.c_int), ("material_bytes", C.c_int), ("feature_mask", C.c_uint),
+                ("device_bytes", C.c_size_t)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+_D = C.c_double
+_DP = C.POINTER(C.c_double)
+_VP = C.c_void_p
+
+# every symbol include/rt_mi355x.h declares: name -> (restype, argtypes)
+ABI = {
+    "rt_last_error": (C.c_char_p, []),
+    "rt_version": (C.c_char_p, []),
+    "rt_device_count": (C.c_int, []),
+    "rt_mat4_identity": (None, [_DP]),
+    "rt_mat4_translation": (None, [_DP, _DP]),
+    "rt_mat4_rotation": (None, [_D, _DP, _DP]),
+    "rt_mat4_multiplied": (None, [_DP, _DP, _DP]),
+    "rt_mat4_determinant": (_D, [_DP]),
+    "rt_mat4_inversed": (C.c_int, [_DP, _DP]),
+    "rt_scene_create": (_VP, []),
+    "rt_scene_destroy": (None, [_VP]),
+    "rt_add_texture_solid": (C.c_int, [_VP, _DP]),
+    "rt_add_texture_checker": (C.c_int, [_VP, C.c_int, C.c_int]),
+    "rt_add_texture_image_rgb8": (C.c_int, [_VP, C.POINTER(C.c_uint8), C.c_int, C.c_int]),
+    "rt_add_material_lambertian": (C.c_int, [_VP, C.c_int]),
+    "rt_add_material_metal": (C.c_int, [_VP, C.c_int, _D]),
+    "rt_add_material_dielectric": (C.c_int, [_VP, _D]),
+    "rt_add_material_diffuse_light": (C.c_int, [_VP, C.c_int]),
+    "rt_add_material_isotropic": (C.c_int, [_VP, C.c_int]),
+    "rt_add_geometry_sphere": (C.c_int, [_VP, _D]),
+    "rt_add_geometry_rectangle": (C.c_int, [_VP, _D, _D]),
+    "rt_add_geometry_cube": (C.c_int, [_VP, _D, _D, _D]),
+    "rt_add_geometry_constant_medium": (C.c_int, [_VP, C.c_int, _D]),
+    "rt_add_sprite": (C.c_int, [_VP, C.c_int, C.c_int, _DP]),
+    "rt_scene_commit": (C.c_int, [_VP, C.c_int]),
+    "rt_camera_perspective": (C.c_int, [C.POINTER(rt_camera), _DP, _DP, _DP, _D, _D, _D, _D]),
+    "rt_render": (C.c_int, [_VP, C.POINTER(rt_camera), C.POINTER(rt_render_params), _DP, C.POINTER(rt_counters)]),
+    "rt_shard_tile_count": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rt_render_tiles_device": (C.c_int, [_VP, C.POINTER(rt_camera), C.POINTER(rt_render_params), _VP, _VP, _VP]),
+    "rt_unpack_tiles_device": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, _VP]),
+    "rt_last_kernel_ms": (C.c_int, [_VP, C.POINTER(C.c_float)]),
+    "rt_tonemap_rgb8": (None, [_DP, C.c_size_t, C.POINTER(C.c_uint8)]),
+    "rt_write_ppm_p3": (C.c_int, [C.c_char_p, _DP, C.c_int, C.c_int]),
+    "rt_scene_get_info": (C.c_int, [_VP, C.POINTER(rt_scene_info)]),
+    "rt_scene_copy_nodes": (C.c_int, [_VP, _DP, C.c_int]),
+    "rt_scene_prim_bounds": (C.c_int, [_VP, C.c_int, _DP]),
+    "rt_probe_device_math": (C.c_int, [C.c_int, _DP, _DP, C.c_int, _DP, _DP]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load librt_mi355x.so (fails loudly if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise FileNotFoundError(
+                f"{LIB_PATH} is missing: build it with `make -C ray-tracer_amd/csrc` "
+                "(or __graft_entry__.build()); there is no fallback path")
+        L = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in ABI.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc: int) -> int:
+    if rc < 0:
+        raise RtError(rc, lib().rt_last_error().decode())
+    return rc
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(_DP)
+
+
+def _vec(v, n=3):
+    a = np.ascontiguousarray(v, dtype=np.float64)
+    assert a.shape == (n,)
+    return a
+
+
+# ---------------------------------------------------------------- Mat4 (src/mat4.rs)
+class Mat4:
+    """Column-major 4x4, the subset the examples use (src/mat4.rs:21-47,52-80,85-143)."""
+
+    def __init__(self, a):
+        self.a = np.ascontiguousarray(a, dtype=np.float64).reshape(16)
+
+    @staticmethod
+    def identity():
+        out = np.empty(16)
+        lib().rt_mat4_identity(_dp(out))
+        return Mat4(out)
+
+    @staticmethod
+    def translation(offset):
+        out = np.empty(16)
+        lib().rt_mat4_translation(_dp(_vec(offset)), _dp(out))
+        return Mat4(out)
+
+    @staticmethod
+    def rotation(radians, axis):
+        out = np.empty(16)
+        lib().rt_mat4_rotation(float(radians), _dp(_vec(axis)), _dp(out))
+        return Mat4(out)
+
+    def multiplied(self, other: "Mat4"):
+        out = np.empty(16)
+        lib().rt_mat4_multiplied(_dp(self.a), _dp(other.a), _dp(out))
+        return Mat4(out)
+
+    def determinant(self):
+        return float(lib().rt_mat4_determinant(_dp(self.a)))
+
+    def inversed(self):
+        out = np.empty(16)
+        rc = lib().rt_mat4_inversed(_dp(self.a), _dp(out))
+        return None if rc != 0 else Mat4(out)
+
+
+# ---------------------------------------------------------------- scene
+class Scene:
+    """Records textures / materials / geometries / sprites through the C ABI."""
+
+    def __init__(self):
+        self._h = lib().rt_scene_create()
+        self.committed = False
+
+    def close(self):
+        if self._h:
+            lib().rt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # textures
+    def solid(self, rgb):
+        return _check(lib().rt_add_texture_solid(self._h, _dp(_vec(rgb))))
+
+    def checker(self, black, white):
+        return _check(lib().rt_add_texture_checker(self._h, black, white))
+
+    def image(self, rgb8: np.ndarray):
+        a = np.ascontiguousarray(rgb8, dtype=np.uint8)
+        h, w, c = a.shape
+        assert c == 3
+        return _check(lib().rt_add_texture_image_rgb8(self._h, a.ctypes.data_as(C.POINTER(C.c_uint8)), w, h))
+
+    # materials
+    def lambertian(self, tex):
+        return _check(lib().rt_add_material_lambertian(self._h, tex))
+
+    def metal(self, tex, fuzz):
+        return _check(lib().rt_add_material_metal(self._h, tex, float(fuzz)))
+
+    def dielectric(self, refractive):
+        return _check(lib().rt_add_material_dielectric(self._h, float(refractive)))
+
+    def diffuse_light(self, tex):
+        return _check(lib().rt_add_material_diffuse_light(self._h, tex))
+
+    def isotropic(self, tex):
+        return _check(lib().rt_add_material_isotropic(self._h, tex))
+
+    # geometries
+    def sphere(self, r):
+        return _check(lib().rt_add_geometry_sphere(self._h, float(r)))
+
+    def rectangle(self, w, h):
+        return _check(lib().rt_add_geometry_rectangle(self._h, float(w), float(h)))
+
+    def cube(self, w, h, d):
+        return _check(lib().rt_add_geometry_cube(self._h, float(w), float(h), float(d)))
+
+    def constant_medium(self, boundary, density):
+        return _check(lib().rt_add_geometry_constant_medium(self._h, boundary, float(density)))
+
+    def sprite(self, geometry, material, transform=None):
+        m = None if transform is None else _dp(np.ascontiguousarray(transform, dtype=np.float64).reshape(16))
+        return _check(lib().rt_add_sprite(self._h, -1 if geometry is None else geometry,
+                                          -1 if material is None else material, m))
+
+    def commit(self, device: int = 0):
+        _check(lib().rt_scene_commit(self._h, device))
+        self.committed = True
+        return self
+
+    def info(self) -> dict:
+        i = rt_scene_info()
+        _check(lib().rt_scene_get_info(self._h, C.byref(i)))
+        return i.as_dict()
+
+    def nodes(self) -> np.ndarray:
+        n = self.info()["n_nodes"]
+        out = np.zeros((n, 16))
+        _check(lib().rt_scene_copy_nodes(self._h, _dp(out), n))
+        return out
+
+    def prim_bounds(self, i) -> np.ndarray:
+        out = np.zeros(6)
+        _check(lib().rt_scene_prim_bounds(self._h, i, _dp(out)))
+        return out
+
+    # rendering
+    def render(self, cam: "Camera", width, height, spp, max_depth, seed=1, shard=(0, 1), counters=False):
+        """rt_render -> (H, W, 3) float64 image, y up (row 0 = bottom); optionally counters dict."""
+        p = rt_render_params(width, height, spp, max_depth, seed, shard[0], shard[1], 0)
+        out = np.zeros((height, width, 3))
+        cnt = rt_counters() if counters else None
+        _check(lib().rt_render(self._h, C.byref(cam.c), C.byref(p), _dp(out), C.byref(cnt) if counters else None))
+        return (out, cnt.as_dict()) if counters else out
+
+    def render_tiles_device(self, cam: "Camera", width, height, spp, max_depth, seed, shard, d_out_ptr, d_counters_ptr=None,
+                            stream_ptr=None, flags=0):
+        p = rt_render_params(width, height, spp, max_depth, seed, shard[0], shard[1], flags)
+        _check(lib().rt_render_tiles_device(self._h, C.byref(cam.c), C.byref(p), d_out_ptr, d_counters_ptr, stream_ptr))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        _check(lib().rt_last_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+
+class Camera:
+    """PerspectiveCamera::new(eye, center, up, fov, aspect, focusDistance, lensRadius) (src/camera.rs:25-33)."""
+
+    def __init__(self, eye, center, up, fov, aspect, focus_distance, lens_radius):
+        self.c = rt_camera()
+        self.args = (tuple(eye), tuple(center), tuple(up), float(fov), float(aspect), float(focus_distance), float(lens_radius))
+        _check(lib().rt_camera_perspective(C.byref(self.c), _dp(_vec(eye)), _dp(_vec(center)), _dp(_vec(up)), float(fov),
+                                           float(aspect), float(focus_distance), float(lens_radius)))
+
+
+def shard_tile_count(width, height, shard_index, shard_count) -> int:
+    return _check(lib().rt_shard_tile_count(width, height, shard_index, shard_count))
+
+
+def unpack_tiles_device(d_gathered_ptr, tiles_per_shard_padded, shard_count, width, height, d_image_ptr, stream_ptr=None):
+    _check(lib().rt_unpack_tiles_device(d_gathered_ptr, tiles_per_shard_padded, shard_count, width, height, d_image_ptr,
+                                        stream_ptr))
+
+
+def tonemap_rgb8(img: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(img, dtype=np.float64)
+    out = np.zeros(a.shape, dtype=np.uint8)
+    lib().rt_tonemap_rgb8(_dp(a), a.size // 3, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
+def write_ppm_p3(path, img: np.ndarray):
+    a = np.ascontiguousarray(img, dtype=np.float64)
+    h, w, _ = a.shape
+    _check(lib().rt_write_ppm_p3(os.fsencode(str(path)), _dp(a), w, h))
+
+
+def device_count() -> int:
+    return int(lib().rt_device_count())
+
+
+def probe_device_math(a: np.ndarray, b: np.ndarray, device=0):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    s = np.zeros_like(a)
+    d = np.zeros_like(a)
+    _check(lib().rt_probe_device_math(device, _dp(a), _dp(b), a.size, _dp(s), _dp(d)))
+    return s, d

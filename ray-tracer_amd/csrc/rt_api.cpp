@@ -1,0 +1,476 @@
+// rt_api.cpp -- the C ABI of librt_mi355x.so (include/rt_mi355x.h): scene
+// recording, commit (flatten + upload), render launches, output helpers.
+// There is no CPU rendering path here: without a HIP device rt_render* fail
+// with RT_ERR_DEVICE.
+
+#include "../../include/rt_mi355x.h"
+#include "../../include/rt_rng.h"
+#include "rt_host.h"
+#include "rt_scene_priv.h"
+#include "rt_types.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+extern "C" int rt_launch_render(const RtLaunch *L, unsigned features, int lens, int count, void *stream);
+extern "C" int rt_launch_unpack(const double *gathered, int tiles_per_shard, int shard_count, int width, int height,
+                                double *image, void *stream);
+extern "C" int rt_launch_probe_math(const double *a, const double *b, int n, double *out_sqrt, double *out_div, void *stream);
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char *what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return RT_ERR_DEVICE;
+}
+#define HIP_TRY(call)                                   \
+    do {                                                \
+        hipError_t e_ = (call);                         \
+        if (e_ != hipSuccess) return hip_fail(e_, #call); \
+    } while (0)
+
+template <class T>
+int upload(const std::vector<T> &v, void **dptr, size_t *total) {
+    *dptr = nullptr;
+    if (v.empty()) return RT_OK;
+    const size_t bytes = v.size() * sizeof(T);
+    HIP_TRY(hipMalloc(dptr, bytes));
+    HIP_TRY(hipMemcpy(*dptr, v.data(), bytes, hipMemcpyHostToDevice));
+    *total += bytes;
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_err.c_str(); }
+const char *rt_version(void) { return "rt_mi355x 0.1 (gfx950, f64)"; }
+
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void rt_mat4_identity(double out[16]) { rt::mat4_identity(out); }
+void rt_mat4_translation(const double offset[3], double out[16]) { rt::mat4_translation(offset, out); }
+void rt_mat4_rotation(double radians, const double axis[3], double out[16]) { rt::mat4_rotation(radians, axis, out); }
+void rt_mat4_multiplied(const double self[16], const double other[16], double out[16]) { rt::mat4_multiplied(self, other, out); }
+double rt_mat4_determinant(const double m[16]) { return rt::mat4_determinant(m); }
+int rt_mat4_inversed(const double m[16], double out[16]) {
+    return rt::mat4_inversed(m, out) ? RT_OK : fail(RT_ERR_INVALID, "singular matrix (det == 0): Mat4::inversed is None");
+}
+
+rt_scene *rt_scene_create(void) { return new rt_scene; }
+void rt_scene_destroy(rt_scene *s) {
+    if (!s) return;
+    s->release_device();
+    delete s;
+}
+
+static int check_open(rt_scene *s) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    if (s->committed) return fail(RT_ERR_STATE, "scene is immutable after rt_scene_commit");
+    return RT_OK;
+}
+static bool tex_ok(const rt_scene *s, int t) { return t >= 0 && (size_t)t < s->ir.textures.size(); }
+
+int rt_add_texture_solid(rt_scene *s, const double rgb[3]) {
+    if (int e = check_open(s)) return e;
+    if (!rgb) return fail(RT_ERR_INVALID, "rgb is null");
+    rt::TextureIR t{};
+    t.kind = RT_TEX_SOLID;
+    for (int i = 0; i < 3; ++i) t.rgb[i] = rgb[i];
+    s->ir.textures.push_back(t);
+    return (int)s->ir.textures.size() - 1;
+}
+int rt_add_texture_checker(rt_scene *s, int black, int white) {
+    if (int e = check_open(s)) return e;
+    if (!tex_ok(s, black) || !tex_ok(s, white)) return fail(RT_ERR_INVALID, "checker: unknown texture id");
+    rt::TextureIR t{};
+    t.kind = RT_TEX_CHECKER;
+    t.a = black;
+    t.b = white;
+    s->ir.textures.push_back(t);
+    return (int)s->ir.textures.size() - 1;
+}
+int rt_add_texture_image_rgb8(rt_scene *s, const uint8_t *rgb, int w, int h) {
+    if (int e = check_open(s)) return e;
+    if (!rgb || w <= 0 || h <= 0) return fail(RT_ERR_INVALID, "image texture: null data or empty size");
+    rt::TextureIR t{};
+    t.kind = RT_TEX_IMAGE;
+    t.w = w;
+    t.h = h;
+    t.texels.assign(rgb, rgb + (size_t)w * (size_t)h * 3);
+    s->ir.textures.push_back(t);
+    return (int)s->ir.textures.size() - 1;
+}
+
+static int add_material(rt_scene *s, uint32_t kind, int tex, double param, bool needs_tex) {
+    if (int e = check_open(s)) return e;
+    if (needs_tex && !tex_ok(s, tex)) return fail(RT_ERR_INVALID, "material: unknown texture id");
+    s->ir.materials.push_back(rt::MaterialIR{kind, tex, param});
+    return (int)s->ir.materials.size() - 1;
+}
+int rt_add_material_lambertian(rt_scene *s, int tex) { return add_material(s, RT_MAT_LAMBERTIAN, tex, 0.0, true); }
+int rt_add_material_metal(rt_scene *s, int tex, double fuzz) { return add_material(s, RT_MAT_METAL, tex, fuzz, true); }
+int rt_add_material_dielectric(rt_scene *s, double refractive) { return add_material(s, RT_MAT_DIELECTRIC, -1, refractive, false); }
+int rt_add_material_diffuse_light(rt_scene *s, int tex) { return add_material(s, RT_MAT_DIFFUSE_LIGHT, tex, 0.0, true); }
+int rt_add_material_isotropic(rt_scene *s, int tex) { return add_material(s, RT_MAT_ISOTROPIC, tex, 0.0, true); }
+
+static int add_geometry(rt_scene *s, rt::GeometryKind k, double a, double b, double c, int boundary) {
+    if (int e = check_open(s)) return e;
+    rt::GeometryIR g{};
+    g.kind = k;
+    g.p[0] = a;
+    g.p[1] = b;
+    g.p[2] = c;
+    g.boundary = boundary;
+    s->ir.geometries.push_back(g);
+    return (int)s->ir.geometries.size() - 1;
+}
+int rt_add_geometry_sphere(rt_scene *s, double r) { return add_geometry(s, rt::GEO_SPHERE, r, 0, 0, -1); }
+int rt_add_geometry_rectangle(rt_scene *s, double w, double h) { return add_geometry(s, rt::GEO_RECTANGLE, w, h, 0, -1); }
+int rt_add_geometry_cube(rt_scene *s, double w, double h, double d) { return add_geometry(s, rt::GEO_CUBE, w, h, d, -1); }
+int rt_add_geometry_constant_medium(rt_scene *s, int boundary, double density) {
+    if (int e = check_open(s)) return e;
+    if (boundary < 0 || (size_t)boundary >= s->ir.geometries.size()) return fail(RT_ERR_INVALID, "medium: unknown boundary geometry");
+    if (s->ir.geometries[(size_t)boundary].kind != rt::GEO_SPHERE)
+        return fail(RT_ERR_UNSUPPORTED, "medium: only a sphere boundary is supported (the reference's examples use nothing else)");
+    return add_geometry(s, rt::GEO_MEDIUM, density, 0, 0, boundary);
+}
+
+int rt_add_sprite(rt_scene *s, int geometry, int material, const double M[16]) {
+    if (int e = check_open(s)) return e;
+    if (geometry >= (int)s->ir.geometries.size()) return fail(RT_ERR_INVALID, "sprite: unknown geometry id");
+    if (material >= (int)s->ir.materials.size()) return fail(RT_ERR_INVALID, "sprite: unknown material id");
+    rt::SpriteIR sp{};
+    sp.geometry = geometry < 0 ? -1 : geometry;
+    sp.material = material < 0 ? -1 : material;
+    if (M)
+        std::memcpy(sp.M, M, sizeof sp.M);
+    else
+        rt::mat4_identity(sp.M);
+    s->ir.sprites.push_back(sp);
+    return (int)s->ir.sprites.size() - 1;
+}
+
+int rt_scene_commit(rt_scene *s, int device) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
+    std::string err;
+    int rc = rt::flatten_scene(s->ir, &s->flat, &err);
+    if (rc != RT_OK) return fail(rc, err);
+    if (device >= 0) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || device >= n)
+            return fail(RT_ERR_DEVICE, "no such HIP device; librt_mi355x has no CPU rendering path");
+        HIP_TRY(hipSetDevice(device));
+        s->device = device;
+        size_t total = 0;
+        if ((rc = upload(s->flat.nodes, &s->d_nodes, &total))) return rc;
+        if ((rc = upload(s->flat.prims, &s->d_prims, &total))) return rc;
+        if ((rc = upload(s->flat.xforms, &s->d_xforms, &total))) return rc;
+        if ((rc = upload(s->flat.materials, &s->d_materials, &total))) return rc;
+        if ((rc = upload(s->flat.textures, &s->d_textures, &total))) return rc;
+        if ((rc = upload(s->flat.image_blob, &s->d_blob, &total))) return rc;
+        s->device_bytes = total;
+        HIP_TRY(hipEventCreate(&s->ev0));
+        HIP_TRY(hipEventCreate(&s->ev1));
+        s->have_events = true;
+    }
+    s->committed = true;
+    return RT_OK;
+}
+
+int rt_camera_perspective(rt_camera *out, const double eye[3], const double center[3], const double up[3], double fov,
+                          double aspect, double focus, double lens) {
+    if (!out || !eye || !center || !up) return fail(RT_ERR_INVALID, "camera: null argument");
+    RtCameraD c;
+    rt::camera_perspective(&c, eye, center, up, fov, aspect, focus, lens);
+    for (int i = 0; i < 3; ++i) {
+        out->eye[i] = c.eye[i];
+        out->lower_left[i] = c.lower_left[i];
+        out->horizontal[i] = c.horizontal[i];
+        out->vertical[i] = c.vertical[i];
+    }
+    out->lens_radius = c.lens_radius;
+    return RT_OK;
+}
+
+static int tiles_x_of(int w) { return (w + RT_TILE - 1) / RT_TILE; }
+static int tiles_y_of(int h) { return (h + RT_TILE - 1) / RT_TILE; }
+
+int rt_shard_tile_count(int width, int height, int shard_index, int shard_count) {
+    if (width <= 0 || height <= 0 || shard_count <= 0 || shard_index < 0 || shard_index >= shard_count)
+        return fail(RT_ERR_INVALID, "bad image size or shard");
+    const long total = (long)tiles_x_of(width) * tiles_y_of(height);
+    if (shard_index >= total) return 0;
+    return (int)((total - shard_index + shard_count - 1) / shard_count);
+}
+
+static int check_params(const rt_scene *s, const rt_camera *cam, const rt_render_params *p) {
+    if (!s || !cam || !p) return fail(RT_ERR_INVALID, "null argument");
+    if (!s->committed) return fail(RT_ERR_STATE, "rt_scene_commit has not been called");
+    if (s->device < 0) return fail(RT_ERR_DEVICE, "scene was committed host-only (device = -1); librt_mi355x has no CPU rendering path");
+    if (p->width <= 0 || p->height <= 0 || p->spp <= 0 || p->max_depth < 0) return fail(RT_ERR_INVALID, "bad width/height/spp/max_depth");
+    if (p->shard_count <= 0 || p->shard_index < 0 || p->shard_index >= p->shard_count) return fail(RT_ERR_INVALID, "bad shard");
+    if ((uint64_t)p->width * (uint64_t)p->height * (uint64_t)p->spp >= (1ull << 40))
+        return fail(RT_ERR_INVALID, "width*height*spp must stay below 2^40 sample streams (include/rt_rng.h)");
+    return RT_OK;
+}
+
+static void fill_launch(const rt_scene *s, const rt_camera *cam, const rt_render_params *p, int n_owned, double *d_out,
+                        void *d_counters, RtLaunch *L) {
+    std::memset(L, 0, sizeof *L);
+    L->nodes = (const RtNode *)s->d_nodes;
+    L->prims = (const RtPrim *)s->d_prims;
+    L->xforms = (const RtXform *)s->d_xforms;
+    L->materials = (const RtMaterial *)s->d_materials;
+    L->textures = (const RtTexture *)s->d_textures;
+    L->image_blob = (const uint8_t *)s->d_blob;
+    L->root = s->flat.root;
+    L->n_prims = s->flat.n_leaf_prims;
+    for (int i = 0; i < 3; ++i) {
+        L->cam.eye[i] = cam->eye[i];
+        L->cam.lower_left[i] = cam->lower_left[i];
+        L->cam.horizontal[i] = cam->horizontal[i];
+        L->cam.vertical[i] = cam->vertical[i];
+    }
+    L->cam.lens_radius = cam->lens_radius;
+    L->width = p->width;
+    L->height = p->height;
+    L->spp = p->spp;
+    L->max_depth = p->max_depth;
+    L->seed_mix = rt_mix64(p->seed);
+    L->tiles_x = tiles_x_of(p->width);
+    L->tiles_y = tiles_y_of(p->height);
+    L->shard_index = p->shard_index;
+    L->shard_count = p->shard_count;
+    L->n_owned_tiles = n_owned;
+    L->out = d_out;
+    L->counters = (RtCounters *)d_counters;
+}
+
+static unsigned kernel_features(const rt_scene *s) {
+    unsigned f = 0;
+    if (s->flat.feature_mask & RT_FEAT_GENERAL) f |= 1u;
+    if (s->flat.feature_mask & RT_FEAT_MEDIUM) f |= 2u;
+    if (s->flat.feature_mask & RT_FEAT_TEXTURED) f |= 4u;
+    return f;
+}
+
+int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_render_params *p, void *d_tiles_out, void *d_counters,
+                           void *stream) {
+    if (int e = check_params(s, cam, p)) return e;
+    if (!d_tiles_out) return fail(RT_ERR_INVALID, "null output buffer");
+    HIP_TRY(hipSetDevice(s->device));
+    const int n_owned = rt_shard_tile_count(p->width, p->height, p->shard_index, p->shard_count);
+    if (n_owned < 0) return n_owned;
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(s->mu);
+    HIP_TRY(hipEventRecord(s->ev0, st));
+    if (p->max_depth == 0 || n_owned == 0) {
+        // color(ray, world, 0) is black before anything is traced (src/render.rs:6-8)
+        if (n_owned) HIP_TRY(hipMemsetAsync(d_tiles_out, 0, (size_t)n_owned * RT_TILE_PIXELS * 3 * sizeof(double), st));
+    } else {
+        RtLaunch L;
+        fill_launch(s, cam, p, n_owned, (double *)d_tiles_out, d_counters, &L);
+        const bool count = (p->flags & RT_FLAG_COUNTERS) && d_counters;
+        int rc = rt_launch_render(&L, kernel_features(s), cam->lens_radius != 0.0, count, stream);
+        if (rc != 0) return hip_fail((hipError_t)rc, "render_kernel launch");
+    }
+    HIP_TRY(hipEventRecord(s->ev1, st));
+    s->timed = true;
+    return RT_OK;
+}
+
+int rt_last_kernel_ms(rt_scene *s, float *ms) {
+    if (!s || !ms) return fail(RT_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (!s->timed) return fail(RT_ERR_STATE, "no render has been launched on this scene");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventSynchronize(s->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, s->ev0, s->ev1));
+    return RT_OK;
+}
+
+int rt_render(rt_scene *s, const rt_camera *cam, const rt_render_params *p, double *out_rgb, rt_counters *counters) {
+    if (int e = check_params(s, cam, p)) return e;
+    if (!out_rgb) return fail(RT_ERR_INVALID, "null output buffer");
+    HIP_TRY(hipSetDevice(s->device));
+    const int n_owned = rt_shard_tile_count(p->width, p->height, p->shard_index, p->shard_count);
+    if (n_owned < 0) return n_owned;
+    if (counters) std::memset(counters, 0, sizeof *counters);
+    if (n_owned == 0) return RT_OK;
+    const size_t n_doubles = (size_t)n_owned * RT_TILE_PIXELS * 3;
+    double *d_out = nullptr;
+    RtCounters *d_cnt = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_out, n_doubles * sizeof(double)));
+    rt_render_params q = *p;
+    int rc = RT_OK;
+    if (counters) {
+        if (hipMalloc((void **)&d_cnt, sizeof(RtCounters)) != hipSuccess || hipMemset(d_cnt, 0, sizeof(RtCounters)) != hipSuccess)
+            rc = fail(RT_ERR_DEVICE, "counter allocation failed");
+        q.flags |= RT_FLAG_COUNTERS;
+    } else {
+        q.flags &= ~RT_FLAG_COUNTERS;
+    }
+    std::vector<double> host(n_doubles);
+    if (rc == RT_OK) rc = rt_render_tiles_device(s, cam, &q, d_out, d_cnt, nullptr);
+    if (rc == RT_OK) {
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) rc = hip_fail(e, "render_kernel execution");
+    }
+    if (rc == RT_OK) {
+        hipError_t e = hipMemcpy(host.data(), d_out, n_doubles * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "framebuffer copy");
+    }
+    if (rc == RT_OK && counters) {
+        RtCounters c;
+        hipError_t e = hipMemcpy(&c, d_cnt, sizeof c, hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            rc = hip_fail(e, "counter copy");
+        else {
+            counters->samples = c.samples;
+            counters->segments = c.segments;
+            counters->nodes_visited = c.nodes_visited;
+            counters->prims_tested = c.prims_tested;
+            counters->rng_draws = c.rng_draws;
+            counters->wave_iterations = c.wave_iterations;
+            counters->lane_iterations = c.lane_iterations;
+        }
+    }
+    (void)hipFree(d_out);
+    if (d_cnt) (void)hipFree(d_cnt);
+    if (rc != RT_OK) return rc;
+    // scatter the packed tiles into the caller's [y][x][3] image
+    const int tx_n = tiles_x_of(p->width);
+    for (int k = 0; k < n_owned; ++k) {
+        const int tile = p->shard_index + k * p->shard_count;
+        const int tx = tile % tx_n, ty = tile / tx_n;
+        for (int lane = 0; lane < RT_TILE_PIXELS; ++lane) {
+            const int x = tx * RT_TILE + (lane & 7), y = ty * RT_TILE + (lane >> 3);
+            if (x >= p->width || y >= p->height) continue;
+            const double *src = &host[((size_t)k * RT_TILE_PIXELS + (size_t)lane) * 3];
+            double *dst = out_rgb + ((size_t)y * (size_t)p->width + (size_t)x) * 3;
+            dst[0] = src[0];
+            dst[1] = src[1];
+            dst[2] = src[2];
+        }
+    }
+    return RT_OK;
+}
+
+int rt_unpack_tiles_device(const void *d_gathered, int tiles_per_shard_padded, int shard_count, int width, int height,
+                           void *d_image_out, void *stream) {
+    if (!d_gathered || !d_image_out || tiles_per_shard_padded <= 0 || shard_count <= 0 || width <= 0 || height <= 0)
+        return fail(RT_ERR_INVALID, "bad argument");
+    int rc = rt_launch_unpack((const double *)d_gathered, tiles_per_shard_padded, shard_count, width, height, (double *)d_image_out,
+                              stream);
+    if (rc != 0) return hip_fail((hipError_t)rc, "unpack_kernel launch");
+    return RT_OK;
+}
+
+void rt_tonemap_rgb8(const double *rgb, size_t n_pixels, uint8_t *out) {
+    for (size_t i = 0; i < n_pixels * 3; ++i) out[i] = rt::tonemap_channel(rgb[i]);
+}
+
+int rt_write_ppm_p3(const char *path, const double *rgb, int width, int height) { // examples/book-one.rs:28-30,90-100
+    if (!path || !rgb || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "bad argument");
+    FILE *f = std::fopen(path, "w");
+    if (!f) return fail(RT_ERR_INVALID, std::string("cannot open ") + path);
+    std::fprintf(f, "P3\n%d %d\n255\n", width, height);
+    for (int y = height - 1; y >= 0; --y) // rows top-down while y is up
+        for (int x = 0; x < width; ++x) {
+            const double *px = rgb + ((size_t)y * (size_t)width + (size_t)x) * 3;
+            std::fprintf(f, "%u %u %u\n", (unsigned)rt::tonemap_channel(px[0]), (unsigned)rt::tonemap_channel(px[1]),
+                         (unsigned)rt::tonemap_channel(px[2]));
+        }
+    std::fclose(f);
+    return RT_OK;
+}
+
+int rt_scene_get_info(const rt_scene *s, rt_scene_info *out) {
+    if (!s || !out) return fail(RT_ERR_INVALID, "null argument");
+    if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
+    std::memset(out, 0, sizeof *out);
+    out->n_prims = s->flat.n_leaf_prims;
+    out->n_child_prims = (int)s->flat.prims.size() - s->flat.n_leaf_prims;
+    out->n_nodes = (int)s->flat.nodes.size();
+    out->max_depth = s->flat.max_depth;
+    out->n_materials = (int)s->flat.materials.size();
+    out->n_textures = (int)s->flat.textures.size();
+    out->n_xforms = (int)s->flat.xforms.size();
+    out->node_bytes = (int)sizeof(RtNode);
+    out->prim_bytes = (int)sizeof(RtPrim);
+    out->material_bytes = (int)sizeof(RtMaterial);
+    out->feature_mask = s->flat.feature_mask;
+    out->device_bytes = s->device_bytes;
+    return RT_OK;
+}
+
+int rt_scene_copy_nodes(const rt_scene *s, double *out, int max_nodes) {
+    if (!s || !out) return fail(RT_ERR_INVALID, "null argument");
+    if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
+    const int n = (int)s->flat.nodes.size();
+    for (int i = 0; i < n && i < max_nodes; ++i) {
+        const RtNode &nd = s->flat.nodes[(size_t)i];
+        double *o = out + (size_t)i * 16;
+        for (int k = 0; k < 3; ++k) {
+            o[k] = nd.lo0[k];
+            o[3 + k] = nd.hi0[k];
+            o[6 + k] = nd.lo1[k];
+            o[9 + k] = nd.hi1[k];
+        }
+        o[12] = (double)nd.child0;
+        o[13] = (double)nd.child1;
+        o[14] = o[15] = 0.0;
+    }
+    return n;
+}
+
+int rt_scene_prim_bounds(const rt_scene *s, int prim, double out[6]) {
+    if (!s || !out) return fail(RT_ERR_INVALID, "null argument");
+    if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
+    if (prim < 0 || prim >= s->flat.n_leaf_prims) return fail(RT_ERR_INVALID, "prim out of range");
+    const rt::Aabb &b = s->flat.prim_bounds[(size_t)prim];
+    for (int i = 0; i < 3; ++i) {
+        out[i] = b.lo[i];
+        out[3 + i] = b.hi[i];
+    }
+    return RT_OK;
+}
+
+int rt_probe_device_math(int device, const double *a, const double *b, int n, double *out_sqrt, double *out_div) {
+    if (!a || !b || !out_sqrt || !out_div || n <= 0) return fail(RT_ERR_INVALID, "bad argument");
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || device < 0 || device >= cnt) return fail(RT_ERR_DEVICE, "no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    double *d[4] = {nullptr, nullptr, nullptr, nullptr};
+    const size_t bytes = (size_t)n * sizeof(double);
+    for (auto &p : d) HIP_TRY(hipMalloc((void **)&p, bytes));
+    HIP_TRY(hipMemcpy(d[0], a, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d[1], b, bytes, hipMemcpyHostToDevice));
+    int rc = rt_launch_probe_math(d[0], d[1], n, d[2], d[3], nullptr);
+    if (rc != 0) return hip_fail((hipError_t)rc, "probe kernel launch");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out_sqrt, d[2], bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_div, d[3], bytes, hipMemcpyDeviceToHost));
+    for (auto &p : d) (void)hipFree(p);
+    return RT_OK;
+}
+
+} // extern "C"

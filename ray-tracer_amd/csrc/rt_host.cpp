@@ -1,0 +1,532 @@
+// rt_host.cpp -- host side: Mat4, camera, scene flattener, SAH BVH builder.
+//
+// The reference keeps every object behind trait objects with a Mat4Cached pair
+// each (src/sprite.rs:11-15) and builds a random-axis median-split tree
+// (src/optimize.rs:366-440).  Its traversal neither prunes nor orders
+// (src/optimize.rs:469-498), so the nearest hit does not depend on the tree: the
+// flattener is free to choose its own structure.  It emits
+//   - one 64-byte record per sprite (translation-only sphere sprites -- all of
+//     book-one -- collapse to world-space centre + radius, the arithmetic the
+//     4x4 path performs for a translation matrix, rounding for rounding),
+//   - one SAH-built BVH2 whose nodes carry both child boxes (one fetch per step),
+//   - de-duplicated materials with solid colours inlined.
+// Compile with -ffp-contract=off: matrices and bounds must round like the reference.
+
+#include "rt_host.h"
+
+#include "../../include/rt_mi355x.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+
+namespace rt {
+
+namespace {
+constexpr double kInf = std::numeric_limits<double>::infinity();
+constexpr double kPi = 3.14159265358979323846264338327950288;
+} // namespace
+
+// ------------------------------------------------------------------ Mat4
+void mat4_identity(double out[16]) { // src/mat4.rs:21-28
+    for (int i = 0; i < 16; ++i) out[i] = 0.0;
+    out[0] = out[5] = out[10] = out[15] = 1.0;
+}
+void mat4_translation(const double t[3], double out[16]) { // src/mat4.rs:36-47
+    mat4_identity(out);
+    out[12] = t[0];
+    out[13] = t[1];
+    out[14] = t[2];
+}
+void mat4_rotation(double radians, const double axis[3], double out[16]) { // src/mat4.rs:52-80
+    const double x = axis[0], y = axis[1], z = axis[2];
+    const double s = std::sin(radians), c = std::cos(radians), t = 1.0 - c;
+    out[0] = x * x * t + c;
+    out[1] = y * x * t + z * s;
+    out[2] = z * x * t - y * s;
+    out[3] = 0.0;
+    out[4] = x * y * t - z * s;
+    out[5] = y * y * t + c;
+    out[6] = z * y * t + x * s;
+    out[7] = 0.0;
+    out[8] = x * z * t + y * s;
+    out[9] = y * z * t - x * s;
+    out[10] = z * z * t + c;
+    out[11] = 0.0;
+    out[12] = 0.0;
+    out[13] = 0.0;
+    out[14] = 0.0;
+    out[15] = 1.0;
+}
+void mat4_multiplied(const double self[16], const double other[16], double out[16]) { // src/mat4.rs:85-143
+    double r[16];
+    for (int col = 0; col < 4; ++col) {
+        const double b0 = other[col * 4], b1 = other[col * 4 + 1], b2 = other[col * 4 + 2], b3 = other[col * 4 + 3];
+        for (int row = 0; row < 4; ++row)
+            r[col * 4 + row] = b0 * self[row] + b1 * self[4 + row] + b2 * self[8 + row] + b3 * self[12 + row];
+    }
+    std::memcpy(out, r, sizeof r);
+}
+namespace {
+struct Sub2 { // the twelve 2x2 minors shared by determinant and inverse (src/mat4.rs:166-177)
+    double b[12];
+};
+Sub2 minors(const double a[16]) {
+    Sub2 q;
+    q.b[0] = a[0] * a[5] - a[1] * a[4];
+    q.b[1] = a[0] * a[6] - a[2] * a[4];
+    q.b[2] = a[0] * a[7] - a[3] * a[4];
+    q.b[3] = a[1] * a[6] - a[2] * a[5];
+    q.b[4] = a[1] * a[7] - a[3] * a[5];
+    q.b[5] = a[2] * a[7] - a[3] * a[6];
+    q.b[6] = a[8] * a[13] - a[9] * a[12];
+    q.b[7] = a[8] * a[14] - a[10] * a[12];
+    q.b[8] = a[8] * a[15] - a[11] * a[12];
+    q.b[9] = a[9] * a[14] - a[10] * a[13];
+    q.b[10] = a[9] * a[15] - a[11] * a[13];
+    q.b[11] = a[10] * a[15] - a[11] * a[14];
+    return q;
+}
+} // namespace
+double mat4_determinant(const double a[16]) { // src/mat4.rs:146-181
+    const Sub2 q = minors(a);
+    const double *b = q.b;
+    return b[0] * b[11] - b[1] * b[10] + b[2] * b[9] + b[3] * b[8] - b[4] * b[7] + b[5] * b[6];
+}
+bool mat4_inversed(const double a[16], double out[16]) { // src/mat4.rs:184-243
+    const double det = mat4_determinant(a);
+    if (det == 0.0) return false;
+    const Sub2 q = minors(a);
+    const double *b = q.b;
+    double r[16];
+    r[0] = (a[5] * b[11] - a[6] * b[10] + a[7] * b[9]) / det;
+    r[1] = (a[2] * b[10] - a[1] * b[11] - a[3] * b[9]) / det;
+    r[2] = (a[13] * b[5] - a[14] * b[4] + a[15] * b[3]) / det;
+    r[3] = (a[10] * b[4] - a[9] * b[5] - a[11] * b[3]) / det;
+    r[4] = (a[6] * b[8] - a[4] * b[11] - a[7] * b[7]) / det;
+    r[5] = (a[0] * b[11] - a[2] * b[8] + a[3] * b[7]) / det;
+    r[6] = (a[14] * b[2] - a[12] * b[5] - a[15] * b[1]) / det;
+    r[7] = (a[8] * b[5] - a[10] * b[2] + a[11] * b[1]) / det;
+    r[8] = (a[4] * b[10] - a[5] * b[8] + a[7] * b[6]) / det;
+    r[9] = (a[1] * b[8] - a[0] * b[10] - a[3] * b[6]) / det;
+    r[10] = (a[12] * b[4] - a[13] * b[2] + a[15] * b[0]) / det;
+    r[11] = (a[9] * b[2] - a[8] * b[4] - a[11] * b[0]) / det;
+    r[12] = (a[5] * b[7] - a[4] * b[9] - a[6] * b[6]) / det;
+    r[13] = (a[0] * b[9] - a[1] * b[7] + a[2] * b[6]) / det;
+    r[14] = (a[13] * b[1] - a[12] * b[3] - a[14] * b[0]) / det;
+    r[15] = (a[8] * b[3] - a[9] * b[1] + a[10] * b[0]) / det;
+    std::memcpy(out, r, sizeof r);
+    return true;
+}
+
+// ---------------------------------------------------------------- camera
+void camera_perspective(RtCameraD *out, const double eye[3], const double center[3], const double up_in[3], double fov,
+                        double aspect, double focus, double lens) { // src/camera.rs:25-59
+    auto len = [](const double v[3]) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+    double up[3], w[3], u[3], v[3];
+    const double ul = len(up_in);
+    for (int i = 0; i < 3; ++i) up[i] = up_in[i] / ul;
+    const double height = std::tan(fov / 2.0) * 2.0;
+    const double width = aspect * height;
+    double ec[3] = {eye[0] - center[0], eye[1] - center[1], eye[2] - center[2]};
+    const double el = len(ec);
+    for (int i = 0; i < 3; ++i) w[i] = ec[i] / el;
+    // u = up x w, left un-normalised (quirk Q1); cross per src/vec3.rs:80-86
+    u[0] = up[1] * w[2] - up[2] * w[1];
+    u[1] = -(up[0] * w[2] - up[2] * w[0]);
+    u[2] = up[0] * w[1] - up[1] * w[0];
+    v[0] = w[1] * u[2] - w[2] * u[1];
+    v[1] = -(w[0] * u[2] - w[2] * u[0]);
+    v[2] = w[0] * u[1] - w[1] * u[0];
+    for (int i = 0; i < 3; ++i) {
+        out->eye[i] = eye[i];
+        out->horizontal[i] = u[i] * width * focus;
+        out->vertical[i] = v[i] * height * focus;
+        out->lower_left[i] = eye[i] - out->horizontal[i] / 2.0 - out->vertical[i] / 2.0 - w[i] * focus;
+    }
+    out->lens_radius = lens;
+}
+
+uint8_t tonemap_channel(double c) { // examples/book-one.rs:95-97 (quirk Q13)
+    const double v = std::fmin(std::sqrt(c) * 255.0, 255.0);
+    if (!(v > 0.0)) return 0;
+    return (uint8_t)v;
+}
+
+// ------------------------------------------------------------- flattening
+namespace {
+
+void make_xform(const double M[16], const double Minv[16], RtXform *x) {
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) {
+            x->m[r * 4 + c] = M[c * 4 + r];
+            x->inv[r * 4 + c] = Minv[c * 4 + r];
+        }
+}
+
+// x' = m0*x + m4*y + m8*z + m12*w, evaluated left to right (src/vec4.rs:78-91)
+void xform_point(const double M[16], const double p[3], double out[3]) {
+    for (int r = 0; r < 3; ++r) out[r] = M[r] * p[0] + M[4 + r] * p[1] + M[8 + r] * p[2] + M[12 + r] * 1.0;
+}
+
+// AABB of the eight transformed corners (src/optimize.rs:149-177 = :205-233)
+Aabb transformed_bound(const Aabb &b, const double M[16]) {
+    const double x0 = b.lo[0], y0 = b.lo[1], z0 = b.lo[2], x1 = b.hi[0], y1 = b.hi[1], z1 = b.hi[2];
+    const double c[8][3] = {{x0, y0, z0}, {x1, y0, z0}, {x0, y1, z0}, {x0, y0, z1},
+                            {x1, y1, z0}, {x1, y0, z1}, {x0, y1, z1}, {x1, y1, z1}};
+    Aabb o;
+    for (int i = 0; i < 3; ++i) {
+        o.lo[i] = kInf;
+        o.hi[i] = -kInf;
+    }
+    for (const auto &p : c) {
+        double q[3];
+        xform_point(M, p, q);
+        for (int i = 0; i < 3; ++i) {
+            if (q[i] < o.lo[i]) o.lo[i] = q[i];
+            if (q[i] > o.hi[i]) o.hi[i] = q[i];
+        }
+    }
+    return o;
+}
+Aabb merged(const Aabb &a, const Aabb &b) { // src/optimize.rs:44-57
+    Aabb o;
+    for (int i = 0; i < 3; ++i) {
+        o.lo[i] = std::fmin(a.lo[i], b.lo[i]);
+        o.hi[i] = std::fmax(a.hi[i], b.hi[i]);
+    }
+    return o;
+}
+Aabb sphere_bound(double r) { return Aabb{{-r, -r, -r}, {r, r, r}}; }                                      // src/optimize.rs:105-114
+Aabb rect_bound(double w, double h) { return Aabb{{-w / 2.0, -h / 2.0, -1e-6}, {w / 2.0, h / 2.0, 1e-6}}; } // src/optimize.rs:116-126
+
+// The culling boxes must contain every hit the f64 primitive test can report.
+// Reference bounds are rounded to nearest; pad them by ~2^-40 relative so a
+// grazing hit that only exists through rounding is never culled.
+void pad(Aabb *b) {
+    for (int i = 0; i < 3; ++i) {
+        const double scale = std::fmax(std::fmax(std::fabs(b->lo[i]), std::fabs(b->hi[i])), b->hi[i] - b->lo[i]);
+        const double e = scale * 0x1p-40;
+        b->lo[i] -= e;
+        b->hi[i] += e;
+    }
+}
+
+bool is_pure_translation(const double M[16]) {
+    static const int zero_idx[] = {1, 2, 3, 4, 6, 7, 8, 9, 11};
+    for (int i : zero_idx)
+        if (M[i] != 0.0) return false;
+    return M[0] == 1.0 && M[5] == 1.0 && M[10] == 1.0 && M[15] == 1.0;
+}
+
+// Cube::new (src/geometry.rs:254-286): six TransformedGeometry<Rectangle>
+struct CubeFace {
+    double w, h;
+    double M[16];
+};
+void cube_faces(double width, double height, double depth, CubeFace f[6]) {
+    auto rad = [](double deg) { return deg * (kPi / 180.0); }; // f64::to_radians
+    const double ex[3] = {1.0, 0.0, 0.0}, ey[3] = {0.0, 1.0, 0.0};
+    double T[16], R[16];
+    auto set = [&](int i, double w, double h, const double t[3], bool rot, double deg, const double *axis) {
+        f[i].w = w;
+        f[i].h = h;
+        mat4_translation(t, T);
+        if (rot) {
+            mat4_rotation(rad(deg), axis, R);
+            mat4_multiplied(T, R, f[i].M);
+        } else {
+            std::memcpy(f[i].M, T, sizeof T);
+        }
+    };
+    const double t0[3] = {0.0, 0.0, depth / 2.0}, t1[3] = {-width / 2.0, 0.0, 0.0}, t2[3] = {0.0, 0.0, -depth / 2.0};
+    const double t3[3] = {width / 2.0, 0.0, 0.0}, t4[3] = {0.0, height / 2.0, 0.0}, t5[3] = {0.0, -height / 2.0, 0.0};
+    set(0, width, height, t0, false, 0.0, nullptr); // front
+    set(1, depth, height, t1, true, -90.0, ey);     // left
+    set(2, width, height, t2, true, 180.0, ey);     // back
+    set(3, depth, height, t3, true, 90.0, ey);      // right
+    set(4, width, depth, t4, true, -90.0, ex);      // top
+    set(5, width, depth, t5, true, 90.0, ex);       // bottom
+}
+
+} // namespace
+
+int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
+    FlatScene fs;
+
+    // textures
+    for (const TextureIR &t : ir.textures) {
+        RtTexture d{};
+        d.kind = t.kind;
+        d.a = (uint32_t)t.a;
+        d.b = (uint32_t)t.b;
+        d.w = (uint32_t)t.w;
+        d.h = (uint32_t)t.h;
+        for (int i = 0; i < 3; ++i) d.rgb[i] = t.rgb[i];
+        if (t.kind == RT_TEX_IMAGE) {
+            d.data = (uint32_t)fs.image_blob.size();
+            fs.image_blob.insert(fs.image_blob.end(), t.texels.begin(), t.texels.end());
+            while (fs.image_blob.size() % 16) fs.image_blob.push_back(0);
+        }
+        fs.textures.push_back(d);
+    }
+    // materials
+    for (const MaterialIR &m : ir.materials) {
+        RtMaterial d{};
+        d.kind = m.kind;
+        d.param = m.param;
+        d.tex = 0;
+        d.solid = 1;
+        d.rgb[0] = d.rgb[1] = d.rgb[2] = 1.0; // Dielectric attenuation (src/material.rs:148)
+        if (m.kind != RT_MAT_DIELECTRIC) {
+            const TextureIR &t = ir.textures[(size_t)m.tex];
+            d.tex = (uint32_t)m.tex;
+            if (t.kind == RT_TEX_SOLID) {
+                for (int i = 0; i < 3; ++i) d.rgb[i] = t.rgb[i];
+            } else {
+                d.solid = 0;
+                fs.feature_mask |= RT_FEAT_TEXTURED;
+            }
+        }
+        fs.materials.push_back(d);
+    }
+
+    // sprites -> leaf prims
+    struct PendingGroup {
+        size_t prim;
+        CubeFace faces[6];
+    };
+    std::vector<PendingGroup> groups;
+    uint32_t medium_slots = 0;
+    for (const SpriteIR &s : ir.sprites) {
+        if (s.geometry < 0) continue; // geometry None: never hit (src/sprite.rs:95,136)
+        const GeometryIR &g = ir.geometries[(size_t)s.geometry];
+        uint32_t slot = 0;
+        if (g.kind == GEO_MEDIUM) slot = (medium_slots++) & 0x3FFu; // slots count sprites in creation order
+        double Minv[16];
+        if (!mat4_inversed(s.M, Minv)) continue; // det == 0: unhittable (src/sprite.rs:131-134)
+        RtPrim p{};
+        p.material = s.material < 0 ? RT_NO_MATERIAL : (uint32_t)s.material;
+        const bool trans = is_pure_translation(s.M);
+        Aabb local;
+        switch (g.kind) {
+        case GEO_SPHERE:
+            local = sphere_bound(g.p[0]);
+            if (trans) {
+                p.kind = RT_PRIM_SPHERE_T;
+                p.g[0] = s.M[12];
+                p.g[1] = s.M[13];
+                p.g[2] = s.M[14];
+                p.g[3] = g.p[0];
+                fs.feature_mask |= RT_FEAT_SPHERE_T;
+            } else {
+                p.kind = RT_PRIM_SPHERE_M;
+                p.g[0] = g.p[0];
+                fs.feature_mask |= RT_FEAT_GENERAL;
+            }
+            break;
+        case GEO_RECTANGLE:
+            local = rect_bound(g.p[0], g.p[1]);
+            p.kind = RT_PRIM_RECT_M;
+            p.g[0] = g.p[0];
+            p.g[1] = g.p[1];
+            fs.feature_mask |= RT_FEAT_GENERAL;
+            break;
+        case GEO_CUBE: {
+            PendingGroup pg;
+            pg.prim = fs.prims.size();
+            cube_faces(g.p[0], g.p[1], g.p[2], pg.faces);
+            bool first = true;
+            for (const CubeFace &f : pg.faces) {
+                Aabb fb = transformed_bound(rect_bound(f.w, f.h), f.M);
+                local = first ? fb : merged(local, fb);
+                first = false;
+            }
+            groups.push_back(pg);
+            p.kind = RT_PRIM_GROUP_M;
+            p.g[0] = 6.0;
+            fs.feature_mask |= RT_FEAT_GENERAL;
+            break;
+        }
+        case GEO_MEDIUM: {
+            const GeometryIR &b = ir.geometries[(size_t)g.boundary];
+            local = sphere_bound(b.p[0]);
+            p.aux = slot;
+            if (trans) {
+                p.kind = RT_PRIM_MEDIUM_T;
+                p.g[0] = s.M[12];
+                p.g[1] = s.M[13];
+                p.g[2] = s.M[14];
+                p.g[3] = b.p[0];
+                p.g2[0] = g.p[0];
+            } else {
+                p.kind = RT_PRIM_MEDIUM_M;
+                p.g[0] = b.p[0];
+                p.g[1] = g.p[0];
+            }
+            fs.feature_mask |= RT_FEAT_MEDIUM;
+            break;
+        }
+        }
+        if (p.kind != RT_PRIM_SPHERE_T && p.kind != RT_PRIM_MEDIUM_T) {
+            RtXform x;
+            make_xform(s.M, Minv, &x);
+            p.xform = (uint32_t)fs.xforms.size();
+            fs.xforms.push_back(x);
+        }
+        Aabb wb = transformed_bound(local, s.M);
+        pad(&wb);
+        fs.prims.push_back(p);
+        fs.prim_bounds.push_back(wb);
+    }
+    fs.n_leaf_prims = (int)fs.prims.size();
+    if (fs.n_leaf_prims == 0) {
+        if (err) *err = "empty scene: BoundingVolumeHierarchyNode::new(vec![]) is None (src/optimize.rs:367-370)";
+        return RT_ERR_EMPTY;
+    }
+    // group children (never BVH leaves): TransformedGeometry<Rectangle> records
+    for (const PendingGroup &pg : groups) {
+        fs.prims[pg.prim].aux = (uint32_t)fs.prims.size();
+        int kept = 0;
+        for (const CubeFace &f : pg.faces) {
+            double Minv[16];
+            if (!mat4_inversed(f.M, Minv)) continue;
+            RtPrim c{};
+            c.kind = RT_PRIM_RECT_M;
+            c.material = RT_NO_MATERIAL;
+            c.g[0] = f.w;
+            c.g[1] = f.h;
+            RtXform x;
+            make_xform(f.M, Minv, &x);
+            c.xform = (uint32_t)fs.xforms.size();
+            fs.xforms.push_back(x);
+            fs.prims.push_back(c);
+            fs.prim_bounds.push_back(Aabb{{0, 0, 0}, {0, 0, 0}});
+            ++kept;
+        }
+        fs.prims[pg.prim].g[0] = (double)kept;
+    }
+
+    build_bvh(fs.prim_bounds, fs.n_leaf_prims, &fs.nodes, &fs.root, &fs.max_depth);
+    *out = std::move(fs);
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------- BVH build
+namespace {
+
+struct Builder {
+    const std::vector<Aabb> &bounds;
+    std::vector<RtNode> &nodes;
+    int max_depth = 0;
+
+    static double area(const Aabb &b) {
+        const double dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+        return 2.0 * (dx * dy + dy * dz + dz * dx);
+    }
+    static int ceil_log2(size_t n) {
+        int k = 0;
+        while (((size_t)1 << k) < n) ++k;
+        return k;
+    }
+    Aabb bound_of(const std::vector<int> &ids) const {
+        Aabb b = bounds[(size_t)ids[0]];
+        for (size_t i = 1; i < ids.size(); ++i) b = merged(b, bounds[(size_t)ids[i]]);
+        return b;
+    }
+
+    // returns child reference (node index, or ~prim); `budget` = inner levels still allowed
+    int32_t build(std::vector<int> ids, int depth, int budget, Aabb *box) {
+        *box = bound_of(ids);
+        if (ids.size() == 1) {
+            max_depth = std::max(max_depth, depth);
+            return ~ids[0];
+        }
+        const size_t n = ids.size();
+        size_t best_split = n / 2;
+        int best_axis = 0;
+        double best_cost = kInf;
+        std::vector<int> sorted[3];
+        std::vector<double> right_area(n);
+        for (int axis = 0; axis < 3; ++axis) {
+            sorted[axis] = ids;
+            std::stable_sort(sorted[axis].begin(), sorted[axis].end(), [&](int a, int b) {
+                const double ca = bounds[(size_t)a].lo[axis] + bounds[(size_t)a].hi[axis];
+                const double cb = bounds[(size_t)b].lo[axis] + bounds[(size_t)b].hi[axis];
+                return ca < cb;
+            });
+            const std::vector<int> &s = sorted[axis];
+            Aabb acc = bounds[(size_t)s[n - 1]];
+            right_area[n - 1] = area(acc);
+            for (size_t i = n - 1; i-- > 0;) {
+                acc = merged(acc, bounds[(size_t)s[i]]);
+                right_area[i] = area(acc);
+            }
+            acc = bounds[(size_t)s[0]];
+            for (size_t i = 1; i < n; ++i) { // left = [0,i), right = [i,n)
+                const double cost = area(acc) * (double)i + right_area[i] * (double)(n - i);
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = axis;
+                    best_split = i;
+                }
+                acc = merged(acc, bounds[(size_t)s[i]]);
+            }
+        }
+        // depth guard: both halves must still fit the remaining stack budget
+        const size_t big = std::max(best_split, n - best_split);
+        if (!std::isfinite(best_cost) || (big > 1 && ceil_log2(big) > budget - 1)) best_split = n / 2;
+        const std::vector<int> &s = sorted[best_axis];
+        std::vector<int> left(s.begin(), s.begin() + (long)best_split), right(s.begin() + (long)best_split, s.end());
+
+        const int32_t me = (int32_t)nodes.size();
+        nodes.emplace_back();
+        Aabb lb, rb;
+        const int32_t c0 = build(std::move(left), depth + 1, budget - 1, &lb);
+        const int32_t c1 = build(std::move(right), depth + 1, budget - 1, &rb);
+        RtNode &nd = nodes[(size_t)me];
+        std::memset(&nd, 0, sizeof nd);
+        for (int i = 0; i < 3; ++i) {
+            nd.lo0[i] = lb.lo[i];
+            nd.hi0[i] = lb.hi[i];
+            nd.lo1[i] = rb.lo[i];
+            nd.hi1[i] = rb.hi[i];
+        }
+        nd.child0 = c0;
+        nd.child1 = c1;
+        return me;
+    }
+};
+
+} // namespace
+
+void build_bvh(const std::vector<Aabb> &bounds, int n, std::vector<RtNode> *nodes, int32_t *root, int *max_depth) {
+    nodes->clear();
+    std::vector<int> ids((size_t)n);
+    std::iota(ids.begin(), ids.end(), 0);
+    Builder b{bounds, *nodes};
+    Aabb box;
+    if (n == 1) {
+        // single primitive: one node whose second child is an empty box
+        RtNode nd;
+        std::memset(&nd, 0, sizeof nd);
+        for (int i = 0; i < 3; ++i) {
+            nd.lo0[i] = bounds[0].lo[i];
+            nd.hi0[i] = bounds[0].hi[i];
+            nd.lo1[i] = kInf;
+            nd.hi1[i] = -kInf;
+        }
+        nd.child0 = ~0;
+        nd.child1 = ~0;
+        nodes->push_back(nd);
+        *root = 0;
+        *max_depth = 1;
+        return;
+    }
+    *root = b.build(std::move(ids), 0, RT_STACK_DEPTH - 1, &box);
+    *max_depth = b.max_depth;
+}
+
+} // namespace rt

@@ -1,0 +1,86 @@
+// rt_host.h -- host side of librt_mi355x: scene IR mirroring the reference's
+// builder API, the flattener into SoA device records, and the BVH builder.
+// Pure C++17, no HIP: compiled and unit-tested on CPU-only machines.
+#ifndef RT_HOST_H
+#define RT_HOST_H
+
+#include "rt_types.h"
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace rt {
+
+// ---- Mat4 (src/mat4.rs), column-major ----
+void mat4_identity(double out[16]);
+void mat4_translation(const double t[3], double out[16]);
+void mat4_rotation(double radians, const double axis[3], double out[16]);
+void mat4_multiplied(const double self[16], const double other[16], double out[16]);
+double mat4_determinant(const double m[16]);
+bool mat4_inversed(const double m[16], double out[16]);
+
+struct Aabb {
+    double lo[3], hi[3];
+};
+
+// ---- scene IR: what the rt_add_* calls record ----
+struct TextureIR {
+    uint32_t kind;
+    double rgb[3];
+    int a, b;
+    int w, h;
+    std::vector<uint8_t> texels;
+};
+struct MaterialIR {
+    uint32_t kind;
+    int tex;
+    double param;
+};
+enum GeometryKind { GEO_SPHERE, GEO_RECTANGLE, GEO_CUBE, GEO_MEDIUM };
+struct GeometryIR {
+    GeometryKind kind;
+    double p[3]; // sphere: r | rectangle: w,h | cube: w,h,d | medium: density
+    int boundary;
+};
+struct SpriteIR {
+    int geometry, material;
+    double M[16];
+};
+
+struct FlatScene {
+    std::vector<RtNode> nodes;
+    std::vector<RtPrim> prims; // [0, n_leaf_prims) are BVH leaves, the rest are group children
+    std::vector<Aabb> prim_bounds;
+    std::vector<RtXform> xforms;
+    std::vector<RtMaterial> materials;
+    std::vector<RtTexture> textures;
+    std::vector<uint8_t> image_blob;
+    int32_t root = 0;
+    int n_leaf_prims = 0;
+    int max_depth = 0;
+    unsigned feature_mask = 0;
+};
+
+struct SceneIR {
+    std::vector<TextureIR> textures;
+    std::vector<MaterialIR> materials;
+    std::vector<GeometryIR> geometries;
+    std::vector<SpriteIR> sprites;
+};
+
+// Flatten + build.  Returns 0 or an RT_ERR_* code with `err` filled.
+int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err);
+
+// SAH BVH over prim_bounds[0..n); fills nodes/root/max_depth.  Depth <= RT_STACK_DEPTH.
+void build_bvh(const std::vector<Aabb> &bounds, int n, std::vector<RtNode> *nodes, int32_t *root, int *max_depth);
+
+// PerspectiveCamera::new (src/camera.rs:25-59)
+void camera_perspective(RtCameraD *out, const double eye[3], const double center[3], const double up[3], double fov,
+                        double aspect, double focus, double lens);
+
+uint8_t tonemap_channel(double c);
+
+} // namespace rt
+
+#endif

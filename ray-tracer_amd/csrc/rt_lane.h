@@ -1,0 +1,561 @@
+// rt_lane.h -- the per-lane program of the MI355X path tracer: everything one
+// SIMD lane computes for one path segment (camera ray, BVH traversal, primitive
+// intersection, material scatter), written once as header-only RT_HD functions.
+//
+// rt_kernels.hip instantiates it inside the HIP kernels (the product).  The same
+// header can be compiled for the host by tests/ to diff the lane program against
+// the oracle on machines without a GPU; librt_mi355x.so never contains or calls a
+// host instantiation -- the product path is the HIP kernel or an error.
+//
+// All arithmetic is binary64 in the reference's operation order (each function
+// cites file:line); compile with -ffp-contract=off for bit-comparable results.
+#ifndef RT_LANE_H
+#define RT_LANE_H
+
+#include "../../include/rt_rng.h"
+#include "rt_types.h"
+
+#include <math.h>
+
+namespace rtl {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RTL_INF (__builtin_huge_val())
+#else
+#define RTL_INF (__builtin_huge_val())
+#endif
+#define RTL_PI 3.14159265358979323846264338327950288
+#define RTL_EPS 1e-6 /* src/geometry.rs:57,62,159 */
+
+struct V3 {
+    double x, y, z;
+};
+RT_HD V3 mk(double x, double y, double z) {
+    V3 r;
+    r.x = x;
+    r.y = y;
+    r.z = z;
+    return r;
+}
+RT_HD V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_HD V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_HD V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+RT_HD V3 operator*(V3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+RT_HD V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_HD V3 operator/(V3 a, double s) { return mk(a.x / s, a.y / s, a.z / s); }
+RT_HD V3 adds(V3 a, double s) { return mk(a.x + s, a.y + s, a.z + s); } // Add<f64>, src/vec3.rs:153-163
+RT_HD V3 subs(V3 a, double s) { return mk(a.x - s, a.y - s, a.z - s); } // Sub<f64>, src/vec3.rs:185-195
+RT_HD double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }          // src/vec3.rs:76-78
+RT_HD double length(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }       // src/vec3.rs:88-90
+RT_HD V3 normalized(V3 a) { return a / length(a); }                                 // src/vec3.rs:96-98
+RT_HD V3 reflected(V3 v, V3 n) { return v - n * dot(v, n) * 2.0; }                  // src/vec3.rs:100-102
+RT_HD V3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
+
+// Vec4::transformed for a point / a vector, rows 0..2 (src/vec4.rs:78-91)
+RT_HD V3 xf_point(const double *m, V3 p) {
+    return mk(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3] * 1.0, m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7] * 1.0,
+              m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11] * 1.0);
+}
+RT_HD V3 xf_vector(const double *m, V3 v) {
+    return mk(m[0] * v.x + m[1] * v.y + m[2] * v.z + m[3] * 0.0, m[4] * v.x + m[5] * v.y + m[6] * v.z + m[7] * 0.0,
+              m[8] * v.x + m[9] * v.y + m[10] * v.z + m[11] * 0.0);
+}
+
+struct Rec { // HitRecord, src/ray.rs:36-43 (material lives on the prim)
+    double t;
+    V3 p, n;
+    double u, v;
+};
+
+// ---- per-sample random numbers: include/rt_rng.h ----
+struct Rng {
+    uint64_t base, s;
+    unsigned long long draws;
+};
+RT_HD double rng_unit53(Rng &g) { // rand::random::<f64>()
+    g.s += RT_RNG_GAMMA;
+    ++g.draws;
+    return rt_u64_to_unit53(rt_mix64(g.s));
+}
+RT_HD double rng_range01(Rng &g) { // gen_range(0.0, 1.0)
+    g.s += RT_RNG_GAMMA;
+    ++g.draws;
+    return rt_u64_to_range01(rt_mix64(g.s));
+}
+RT_HD double rng_range11(Rng &g) { // gen_range(-1.0, 1.0)
+    g.s += RT_RNG_GAMMA;
+    ++g.draws;
+    return rt_u64_to_range11(rt_mix64(g.s));
+}
+RT_HD V3 random_in_unit_sphere(Rng &g) { // src/util.rs:6-15
+    V3 p = mk(1.0, 1.0, 1.0);
+    while (dot(p, p) >= 1.0) {
+        double a = rng_unit53(g);
+        double b = rng_unit53(g);
+        double c = rng_unit53(g);
+        p = mk(a * 2.0 - 1.0, b * 2.0 - 1.0, c * 2.0 - 1.0);
+    }
+    return p;
+}
+RT_HD V3 random_in_unit_disk(Rng &g) { // src/util.rs:27-42
+    for (;;) {
+        double a = rng_range11(g);
+        double b = rng_range11(g);
+        V3 p = mk(a, b, 0.0);
+        if (length(p) >= 1.0) continue;
+        return p;
+    }
+}
+
+// ---- PerspectiveCamera::ray (src/camera.rs:91-106) ----
+template <bool LENS>
+RT_HD void camera_ray(const RtCameraD &c, double u, double v, Rng &g, V3 *o, V3 *d) {
+    V3 eye = ld3(c.eye), ll = ld3(c.lower_left), hor = ld3(c.horizontal), ver = ld3(c.vertical);
+    if (!LENS) {
+        *o = eye;
+        *d = normalized(ll + hor * u + ver * v - eye);
+    } else {
+        V3 rd = random_in_unit_disk(g) * c.lens_radius;
+        double offset = rd.x * u + rd.y * v; // scalar built from the screen coordinates (quirk Q2)
+        *o = adds(eye, offset);
+        *d = normalized(subs(ll + hor * u + ver * v - eye, offset));
+    }
+}
+
+// ---- Sphere::hit in the sphere's own frame (src/geometry.rs:43-73) ----
+// oc = local ray origin (centre at 0), a = d.d.  Returns the parametric hit only.
+RT_HD bool sphere_t(V3 oc, V3 d, double a, double radius, double *t_out) {
+    double b = dot(oc, d) * 2.0;
+    double c = dot(oc, oc) - radius * radius;
+    double disc = b * b - 4.0 * a * c;
+    if (disc < 0.0) return false;
+    double sq = sqrt(disc);
+    double t1 = (-b - sq) / (2.0 * a);
+    double t2 = (-b + sq) / (2.0 * a);
+    if (!(t1 < t2)) {
+        double tmp = t1;
+        t1 = t2;
+        t2 = tmp;
+    }
+    double t;
+    if (t1 > RTL_EPS)
+        t = t1;
+    else if (t2 > RTL_EPS)
+        t = t2;
+    else
+        return false;
+    *t_out = t;
+    return true;
+}
+RT_HD void sphere_uv(V3 q, double *u, double *v) { // unitSphereUv, src/geometry.rs:35-39
+    *u = 0.5 + atan2(q.x, q.z) / (2.0 * RTL_PI);
+    *v = 1.0 - acos(q.y) / RTL_PI;
+}
+// full local record for a known t (src/geometry.rs:66-71)
+template <bool UV>
+RT_HD void sphere_finish(V3 oc, V3 d, double radius, double t, Rec *r) {
+    V3 p = oc + d * t;
+    V3 q = p / radius;
+    r->t = t;
+    r->p = p;
+    r->n = normalized(q);
+    r->u = 0.0;
+    r->v = 0.0;
+    if (UV) sphere_uv(q, &r->u, &r->v);
+}
+
+// ---- Rectangle::hit, local frame (src/geometry.rs:153-180) ----
+RT_HD bool rect_hit(V3 o, V3 d, double width, double height, Rec *r) {
+    double a0 = -width / 2.0, a1 = -height / 2.0, b0 = width / 2.0, b1 = height / 2.0;
+    double t = (0.0 - o.z) / d.z;
+    if (isinf(t) || isnan(t) || t < RTL_EPS) return false;
+    double x = o.x + d.x * t;
+    double y = o.y + d.y * t;
+    if (x < a0 || x > b0 || y < a1 || y > b1) return false;
+    r->u = (x - a0) / (b0 - a0);
+    r->v = (y - a1) / (b1 - a1);
+    r->t = t;
+    r->p = o + d * t;
+    r->n = mk(0.0, 0.0, 1.0);
+    return true;
+}
+
+// forward half of Sprite::hit / TransformedGeometry::hit (src/sprite.rs:108-126)
+RT_HD void to_world(const RtXform &x, Rec *r) {
+    r->p = xf_point(x.m, r->p);
+    r->n = xf_vector(x.m, r->n); // M, not M^-T, not renormalised (quirk Q5)
+}
+
+// ---- ConstantMedium<Sphere>::hit, boundary frame (src/volume.rs:46-100) ----
+template <bool UV>
+RT_HD bool medium_hit(V3 oc, V3 d, double radius, double density, uint64_t rng_base, uint32_t segment, uint32_t slot,
+                      unsigned long long *draws, Rec *r) {
+    double a = dot(d, d);
+    double t1;
+    if (!sphere_t(oc, d, a, radius, &t1)) return false;
+    Rec r1;
+    sphere_finish<UV>(oc, d, radius, t1, &r1);
+    if (dot(r1.n, d) < 0.0) {
+        V3 o2 = r1.p + d * 1e-6; // restarted ray
+        double t2;
+        if (!sphere_t(o2, d, a, radius, &t2)) return false;
+        Rec r2;
+        sphere_finish<UV>(o2, d, radius, t2, &r2);
+        double inside = r2.t;
+        ++*draws;
+        double distance = (-1.0 / density) * log(rt_u64_to_range01(rt_rng_keyed_from_base(rng_base, segment, slot)));
+        if (distance > inside) return false;
+        r->u = r1.u + r2.u;
+        r->v = r1.v + r2.v;
+        r->t = r1.t + distance;
+        r->p = o2 + d * (r1.t + distance); // on the restarted ray (quirk Q9)
+        r->n = (r1.n + r2.n) / 2.0;
+        return true;
+    }
+    double inside = r1.t;
+    ++*draws;
+    double distance = (-1.0 / density) * log(rt_u64_to_range01(rt_rng_keyed_from_base(rng_base, segment, slot)));
+    if (distance > inside) return false;
+    r->u = r1.u;
+    r->v = r1.v;
+    r->t = distance;
+    r->p = oc + d * distance;
+    r->n = r1.n;
+    return true;
+}
+
+struct SegCtx { // what a primitive test may need besides the ray
+    uint64_t rng_base;
+    uint32_t segment;
+    unsigned long long draws;
+    unsigned long long prims_tested;
+};
+
+// Intersect primitive `pi` with the world ray; on a hit fill the world-space record.
+// RECORD = false: only r->t is meaningful (traversal); true: full record (shading).
+template <bool GENERAL, bool MEDIUM, bool UV, bool RECORD>
+RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx &sc, Rec *r) {
+    const RtPrim &P = L.prims[pi];
+    const uint32_t kind = (GENERAL || MEDIUM) ? P.kind : (uint32_t)RT_PRIM_SPHERE_T;
+    ++sc.prims_tested;
+    if (kind == RT_PRIM_SPHERE_T) {
+        // Sprite::hit with a translation matrix: M^-1 (o,1) = o - c, M^-1 (d,0) = d,
+        // M (p,1) = p + c, M (n,0) = n  (src/sprite.rs:101-126, src/vec4.rs:78-91)
+        V3 c = mk(P.g[0], P.g[1], P.g[2]);
+        V3 oc = o - c;
+        double t;
+        if (!sphere_t(oc, d, a, P.g[3], &t)) return false;
+        r->t = t;
+        if (RECORD) {
+            sphere_finish<UV>(oc, d, P.g[3], t, r);
+            r->p = r->p + c;
+        }
+        return true;
+    }
+    if (MEDIUM && kind == RT_PRIM_MEDIUM_T) {
+        V3 c = mk(P.g[0], P.g[1], P.g[2]);
+        if (!medium_hit<UV>(o - c, d, P.g[3], P.g2[0], sc.rng_base, sc.segment, P.aux, &sc.draws, r)) return false;
+        if (RECORD) r->p = r->p + c;
+        return true;
+    }
+    if (GENERAL || MEDIUM) {
+        const RtXform &X = L.xforms[P.xform];
+        V3 lo = xf_point(X.inv, o);
+        V3 ld = xf_vector(X.inv, d); // not renormalised (quirk Q5)
+        bool ok = false;
+        if (kind == RT_PRIM_SPHERE_M) {
+            double la = dot(ld, ld);
+            double t;
+            if (sphere_t(lo, ld, la, P.g[0], &t)) {
+                ok = true;
+                r->t = t;
+                if (RECORD) sphere_finish<UV>(lo, ld, P.g[0], t, r);
+            }
+        } else if (kind == RT_PRIM_RECT_M) {
+            ok = rect_hit(lo, ld, P.g[0], P.g[1], r);
+        } else if (kind == RT_PRIM_GROUP_M) {
+            // BoundingVolumeHierarchyNode over the faces (src/optimize.rs:469-498):
+            // nearest face, strict <, first face wins ties; the boxes only filter
+            const uint32_t first = P.aux, count = (uint32_t)P.g[0];
+            double best = RTL_INF;
+            for (uint32_t k = 0; k < count; ++k) {
+                const RtPrim &C = L.prims[first + k];
+                const RtXform &CX = L.xforms[C.xform];
+                V3 co = xf_point(CX.inv, lo);
+                V3 cd = xf_vector(CX.inv, ld);
+                Rec cr;
+                ++sc.prims_tested;
+                if (rect_hit(co, cd, C.g[0], C.g[1], &cr) && cr.t < best) {
+                    best = cr.t;
+                    if (RECORD) to_world(CX, &cr); // TransformedGeometry::hit, src/geometry.rs:228-236
+                    *r = cr;
+                    ok = true;
+                }
+            }
+        } else if (MEDIUM && kind == RT_PRIM_MEDIUM_M) {
+            ok = medium_hit<UV>(lo, ld, P.g[0], P.g[1], sc.rng_base, sc.segment, P.aux, &sc.draws, r);
+        }
+        if (!ok) return false;
+        if (RECORD) to_world(X, r);
+        return true;
+    }
+    return false;
+}
+
+// ---- AxisAlignedBoundingBox::hit (src/optimize.rs:61-82) restricted to [0, tmax]:
+// the reference never prunes by the best hit so far; stopping at tmax cannot change
+// the nearest hit, it only skips boxes that start behind it.  idir = 1/d. ----
+RT_HD bool slab(const double *lo, const double *hi, V3 o, V3 idir, double tmax_in, double *tnear) {
+    double tmin = 0.0, tmax = tmax_in;
+    {
+        double t0 = (lo[0] - o.x) * idir.x, t1 = (hi[0] - o.x) * idir.x;
+        if (idir.x < 0.0) {
+            double s = t0;
+            t0 = t1;
+            t1 = s;
+        }
+        tmin = t0 > tmin ? t0 : tmin;
+        tmax = t1 < tmax ? t1 : tmax;
+        if (tmax < tmin) return false;
+    }
+    {
+        double t0 = (lo[1] - o.y) * idir.y, t1 = (hi[1] - o.y) * idir.y;
+        if (idir.y < 0.0) {
+            double s = t0;
+            t0 = t1;
+            t1 = s;
+        }
+        tmin = t0 > tmin ? t0 : tmin;
+        tmax = t1 < tmax ? t1 : tmax;
+        if (tmax < tmin) return false;
+    }
+    {
+        double t0 = (lo[2] - o.z) * idir.z, t1 = (hi[2] - o.z) * idir.z;
+        if (idir.z < 0.0) {
+            double s = t0;
+            t0 = t1;
+            t1 = s;
+        }
+        tmin = t0 > tmin ? t0 : tmin;
+        tmax = t1 < tmax ? t1 : tmax;
+        if (tmax < tmin) return false;
+    }
+    *tnear = tmin;
+    return true;
+}
+
+// Nearest hit over the flat BVH.  Stack is any type with push(int) / pop() / empty().
+// Result is independent of visiting order: nearest t, ties to the lower prim id.
+template <bool GENERAL, bool MEDIUM, bool UV, class Stack>
+RT_HD bool trace(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Stack &st, unsigned long long *nodes_visited, uint32_t *hit_prim,
+                 double *hit_t) {
+    const double a = dot(d, d);
+    const V3 idir = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    double best_t = RTL_INF;
+    uint32_t best_prim = 0xFFFFFFFFu;
+    int32_t cur = L.root;
+    st.reset();
+    for (;;) {
+        if (cur >= 0) {
+            const RtNode &N = L.nodes[cur];
+            ++*nodes_visited;
+            double n0, n1;
+            const bool h0 = slab(N.lo0, N.hi0, o, idir, best_t, &n0);
+            const bool h1 = slab(N.lo1, N.hi1, o, idir, best_t, &n1);
+            if (h0 && h1) {
+                const bool first0 = !(n1 < n0);
+                st.push(first0 ? N.child1 : N.child0);
+                cur = first0 ? N.child0 : N.child1;
+                continue;
+            }
+            if (h0) {
+                cur = N.child0;
+                continue;
+            }
+            if (h1) {
+                cur = N.child1;
+                continue;
+            }
+        } else {
+            const uint32_t pi = (uint32_t)~cur;
+            Rec r;
+            if (prim_hit<GENERAL, MEDIUM, UV, false>(L, pi, o, d, a, sc, &r)) {
+                if (r.t < best_t || (r.t == best_t && pi < best_prim)) {
+                    best_t = r.t;
+                    best_prim = pi;
+                }
+            }
+        }
+        if (st.empty()) break;
+        cur = st.pop();
+    }
+    *hit_prim = best_prim;
+    *hit_t = best_t;
+    return best_prim != 0xFFFFFFFFu;
+}
+
+// ---- Texture::value (src/material.rs:211-215,235-245; examples/main.rs:267-280) ----
+RT_HD uint32_t as_u32(double x) { // Rust `as u32`: saturating, NaN -> 0
+    if (!(x > 0.0)) return 0u;
+    if (x >= 4294967295.0) return 4294967295u;
+    return (uint32_t)x;
+}
+RT_HD V3 texture_value(const RtLaunch &L, uint32_t tex, double u, double v) {
+    for (int guard = 0; guard < 64; ++guard) {
+        const RtTexture &T = L.textures[tex];
+        if (T.kind == RT_TEX_SOLID) return ld3(T.rgb);
+        if (T.kind == RT_TEX_CHECKER) {
+            double sine = sin(2.0 * RTL_PI * 10.0 * u) * sin(2.0 * RTL_PI * 10.0 * v);
+            tex = sine > 0.0 ? T.a : T.b;
+            continue;
+        }
+        uint32_t px = as_u32(u * (double)T.w);
+        uint32_t py = as_u32((1.0 - v) * (double)T.h);
+        if (px >= T.w) px = T.w - 1; // the reference would panic here (u == 1.0); clamp, see DESIGN.md
+        if (py >= T.h) py = T.h - 1;
+        const uint8_t *t = L.image_blob + T.data + ((size_t)py * T.w + px) * 3;
+        return mk((double)t[0] / 255.0, (double)t[1] / 255.0, (double)t[2] / 255.0);
+    }
+    return mk(0.0, 0.0, 0.0);
+}
+
+RT_HD double schlick(double theta, double n1, double n2) { // src/material.rs:140-143
+    double r0 = pow((n1 - n2) / (n1 + n2), 2.0);
+    return r0 + (1.0 - r0) * pow(1.0 - cos(theta), 5.0);
+}
+
+// Material::scatter + emitted for the hit material (src/material.rs:61-69,99-118,
+// 147-192,291-297,318-325).  Returns true if the path continues with (o, d).
+template <bool TEXTURED>
+RT_HD bool shade(const RtLaunch &L, const RtMaterial &M, const Rec &rec, V3 d_in, Rng &g, V3 *o_out, V3 *d_out, V3 *att,
+                 V3 *emit) {
+    *emit = mk(0.0, 0.0, 0.0);
+    V3 tex = ld3(M.rgb);
+    if (TEXTURED && !M.solid) tex = texture_value(L, M.tex, rec.u, rec.v);
+    *o_out = rec.p;
+    switch (M.kind) {
+    case RT_MAT_LAMBERTIAN:
+        *d_out = normalized(rec.n + random_in_unit_sphere(g));
+        *att = tex;
+        return true;
+    case RT_MAT_METAL: {
+        if (dot(d_in, rec.n) < 0.0) {
+            V3 refl = reflected(normalized(d_in), rec.n);
+            if (M.param == 0.0)
+                *d_out = refl;
+            else
+                *d_out = normalized(refl + random_in_unit_sphere(g) * M.param);
+            *att = tex;
+            return true;
+        }
+        return false; // hit from behind: absorbed (quirk Q6)
+    }
+    case RT_MAT_DIELECTRIC: {
+        *att = mk(1.0, 1.0, 1.0);
+        double ratio;
+        V3 normal = rec.n;
+        if (dot(d_in, rec.n) < 0.0) {
+            ratio = 1.0 / M.param;
+        } else {
+            ratio = M.param;
+            normal = -normal;
+        }
+        // Vec3::refracted, src/vec3.rs:113-124
+        V3 uvn = normalized(d_in);
+        double dt = dot(uvn, normal);
+        double disc = 1.0 - ratio * ratio * (1.0 - dt * dt);
+        if (disc > 0.0) {
+            V3 refr = (d_in - normal * dt) * ratio - normal * sqrt(disc);
+            double theta = acos(-dot(d_in, normal));
+            double u = rng_range01(g);
+            if (u < schlick(theta, ratio, 1.0))
+                *d_out = reflected(d_in, rec.n); // about the un-flipped normal (quirk Q7)
+            else
+                *d_out = normalized(refr);
+        } else {
+            *d_out = reflected(d_in, normal); // total internal reflection: no draw
+        }
+        return true;
+    }
+    case RT_MAT_DIFFUSE_LIGHT:
+        *emit = tex;
+        return false;
+    case RT_MAT_ISOTROPIC:
+        *d_out = normalized(random_in_unit_sphere(g));
+        *att = tex;
+        return true;
+    }
+    return false;
+}
+
+// One whole sample (jitter -> camera ray -> iterative color()); used by the kernel's
+// flattened loop piecewise and by the host diff harness as a whole.
+struct PathState {
+    V3 o, d, T, Lsum;
+    Rng g;
+    int32_t k; // segments traced so far
+};
+
+template <bool LENS>
+RT_HD void start_sample(const RtLaunch &L, uint32_t x, uint32_t y, uint32_t s, PathState *ps) {
+    const uint64_t pixel = (uint64_t)y * (uint64_t)L.width + (uint64_t)x;
+    const uint64_t stream = pixel * (uint64_t)L.spp + (uint64_t)s;
+    ps->g.base = L.seed_mix + (stream << RT_RNG_STREAM_SHIFT) * RT_RNG_GAMMA;
+    ps->g.s = ps->g.base;
+    ps->g.draws = 0;
+    // examples/book-one.rs:71-73
+    double u = ((double)x + rng_range01(ps->g)) / (double)L.width;
+    double v = ((double)y + rng_range01(ps->g)) / (double)L.height;
+    camera_ray<LENS>(L.cam, u, v, ps->g, &ps->o, &ps->d);
+    ps->T = mk(1.0, 1.0, 1.0);
+    ps->Lsum = mk(0.0, 0.0, 0.0);
+    ps->k = 0;
+}
+
+// Trace + shade one segment of render::color (src/render.rs:5-29, iterative form
+// L = sum_k (prod_{j<k} att_j) * e_k).  Returns true when the sample is finished.
+template <bool GENERAL, bool MEDIUM, bool TEXTURED, class Stack>
+RT_HD bool advance_segment(const RtLaunch &L, PathState *ps, Stack &st, unsigned long long *nodes_visited,
+                           unsigned long long *prims_tested) {
+    constexpr bool UV = TEXTURED;
+    SegCtx sc;
+    sc.rng_base = ps->g.base;
+    sc.segment = (uint32_t)ps->k;
+    sc.draws = 0;
+    sc.prims_tested = 0;
+    uint32_t prim;
+    double t;
+    const bool hit = trace<GENERAL, MEDIUM, UV>(L, ps->o, ps->d, sc, st, nodes_visited, &prim, &t);
+    ps->g.draws += sc.draws;
+    *prims_tested += sc.prims_tested;
+    if (!hit) return true; // background is black (src/render.rs:21-28)
+    const uint32_t mat = L.prims[prim].material;
+    if (mat == RT_NO_MATERIAL) return true; // src/render.rs:18-20
+    Rec rec;
+    {
+        const double a = dot(ps->d, ps->d);
+        if (GENERAL || MEDIUM) {
+            SegCtx sc2 = sc;
+            prim_hit<GENERAL, MEDIUM, UV, true>(L, prim, ps->o, ps->d, a, sc2, &rec);
+        } else {
+            const RtPrim &P = L.prims[prim];
+            V3 c = mk(P.g[0], P.g[1], P.g[2]);
+            sphere_finish<UV>(ps->o - c, ps->d, P.g[3], t, &rec);
+            rec.p = rec.p + c;
+        }
+    }
+    V3 o2, d2, att, emit;
+    const RtMaterial &M = L.materials[mat];
+    const bool cont = shade<TEXTURED>(L, M, rec, ps->d, ps->g, &o2, &d2, &att, &emit);
+    if (M.kind == RT_MAT_DIFFUSE_LIGHT) ps->Lsum = ps->Lsum + ps->T * emit;
+    if (!cont) return true;
+    ps->T = ps->T * att;
+    ps->o = o2;
+    ps->d = d2;
+    ps->k += 1;
+    return ps->k >= L.max_depth; // color(.., 0) returns black (src/render.rs:6-8)
+}
+
+} // namespace rtl
+
+#endif

@@ -1,0 +1,272 @@
+"""Scene descriptions of the reference's three example drivers, as neutral data.
+
+Harness glue: a ``SceneDesc`` is plain lists (textures, materials, geometries,
+sprites, camera) that tests/bench feed both to librt_mi355x (``build_product``)
+and to the CPU oracle (tests/oracle_binding.py), so both sides see bit-identical
+inputs.  Generators restate
+
+  * ``randomScene()``  examples/book-one.rs:103-205, camera :35-47
+  * cornell box        examples/cornell-box.rs:31-150
+  * ``finalScene()``   examples/main.rs:156-330, camera :49-61
+
+with the unseedable ``thread_rng()`` replaced by the host stream of
+include/rt_rng.h (stream RT_RNG_SCENE_STREAM of ``scene_seed``).  ``./earthmap.jpg``
+(examples/main.rs:266) is not in the reference repository and cannot be
+downloaded here; ``earth_texture()`` is a deterministic procedural stand-in that
+goes through the same nearest-texel rule.
+"""
+from __future__ import annotations
+
+import math
+import struct
+from dataclasses import dataclass, field
+
+import numpy as np
+
+MASK = (1 << 64) - 1
+GAMMA = 0x9E3779B97F4A7C15
+SCENE_STREAM = (1 << 40) - 1
+
+
+def mix64(z: int) -> int:
+    z &= MASK
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK
+    return z ^ (z >> 31)
+
+
+class HostRng:
+    """Python mirror of include/rt_rng.h (checked against the C definition in tests)."""
+
+    def __init__(self, seed: int, stream: int = SCENE_STREAM):
+        self.base = (mix64(seed) + ((stream << 24) & MASK) * GAMMA) & MASK
+        self.s = self.base
+
+    def next_u64(self) -> int:
+        self.s = (self.s + GAMMA) & MASK
+        return mix64(self.s)
+
+    def gen_range(self, low: float, high: float) -> float:
+        scale = high - low
+        offset = low - scale
+        while True:
+            v12 = struct.unpack("<d", struct.pack("<Q", (self.next_u64() >> 12) | 0x3FF0000000000000))[0]
+            res = v12 * scale + offset  # python floats: separate multiply and add
+            if res < high:
+                return res
+
+
+@dataclass
+class SceneDesc:
+    textures: list = field(default_factory=list)    # ("solid", (r,g,b)) | ("checker", a, b) | ("image", ndarray HxWx3 u8)
+    materials: list = field(default_factory=list)   # ("lambertian", tex) | ("metal", tex, fuzz) | ("dielectric", ior) | ("diffuse_light", tex) | ("isotropic", tex)
+    geometries: list = field(default_factory=list)  # ("sphere", r) | ("rectangle", w, h) | ("cube", w, h, d) | ("medium", geom, density)
+    sprites: list = field(default_factory=list)     # (geom | None, mat | None, M16 list | None)
+    world: list | None = None                       # nesting of sprite ids as the reference nests BVH nodes; None = all sprites flat
+    camera: tuple = ()                              # (eye, center, up, fov, aspect, focus, lens)
+    name: str = ""
+
+    # builder helpers that de-duplicate like shared Arcs
+    def tex_solid(self, rgb):
+        self.textures.append(("solid", tuple(float(c) for c in rgb)))
+        return len(self.textures) - 1
+
+    def mat(self, *m):
+        self.materials.append(tuple(m))
+        return len(self.materials) - 1
+
+    def geom(self, *g):
+        self.geometries.append(tuple(g))
+        return len(self.geometries) - 1
+
+    def sprite(self, g, m, M=None):
+        self.sprites.append((g, m, None if M is None else [float(v) for v in M]))
+        return len(self.sprites) - 1
+
+    def lambertian_rgb(self, rgb):
+        return self.mat("lambertian", self.tex_solid(rgb))
+
+
+# ---- Mat4 in python floats, same operation order as src/mat4.rs (cross-checked in tests) ----
+def mat4_translation(t):
+    m = [0.0] * 16
+    m[0] = m[5] = m[10] = m[15] = 1.0
+    m[12], m[13], m[14] = float(t[0]), float(t[1]), float(t[2])
+    return m
+
+
+def mat4_rotation(radians, axis):
+    x, y, z = axis
+    s, c = math.sin(radians), math.cos(radians)
+    t = 1.0 - c
+    return [x * x * t + c, y * x * t + z * s, z * x * t - y * s, 0.0,
+            x * y * t - z * s, y * y * t + c, z * y * t + x * s, 0.0,
+            x * z * t + y * s, y * z * t - x * s, z * z * t + c, 0.0,
+            0.0, 0.0, 0.0, 1.0]
+
+
+def mat4_multiplied(a, b):
+    out = [0.0] * 16
+    for col in range(4):
+        b0, b1, b2, b3 = b[col * 4:col * 4 + 4]
+        for row in range(4):
+            out[col * 4 + row] = b0 * a[row] + b1 * a[4 + row] + b2 * a[8 + row] + b3 * a[12 + row]
+    return out
+
+
+def radians(deg):  # f64::to_radians
+    return deg * (math.pi / 180.0)
+
+
+# ------------------------------------------------------------------ book-one
+def book_one(scene_seed: int = 1, aspect: float = 1.5) -> SceneDesc:
+    """randomScene() of examples/book-one.rs:103-205 + camera :35-47 (aspect = W/H)."""
+    d = SceneDesc(name="book-one")
+    g = HostRng(scene_seed)
+    sph1000, sph2000, sph02, sph1 = d.geom("sphere", 1000.0), d.geom("sphere", 2000.0), d.geom("sphere", 0.2), d.geom("sphere", 1.0)
+    d.sprite(sph1000, d.lambertian_rgb((0.5, 0.5, 0.5)), mat4_translation((0.0, -1000.0, 0.0)))  # ground
+    d.sprite(sph2000, d.mat("diffuse_light", d.tex_solid((0.5, 0.7, 1.0))), None)                # sky sphere
+    glass = None
+    for a in range(-11, 11):
+        for b in range(-11, 11):
+            which = g.gen_range(0.0, 1.0)
+            cx = float(a) + 0.9 * g.gen_range(0.0, 1.0)
+            cz = float(b) + 0.9 * g.gen_range(0.0, 1.0)
+            dx, dy, dz = cx - 4.0, 0.2 - 0.2, cz - 0.0
+            if math.sqrt(dx * dx + dy * dy + dz * dz) > 0.9:
+                if which < 0.3:
+                    alb = [g.gen_range(0.0, 1.0) for _ in range(3)]
+                    alb = [c * c for c in alb]
+                    m = d.lambertian_rgb(alb)
+                elif which < 0.6:
+                    alb = [g.gen_range(0.5, 1.0) for _ in range(3)]
+                    fuzz = g.gen_range(0.0, 0.5)
+                    m = d.mat("metal", d.tex_solid(alb), fuzz)
+                else:
+                    m = d.mat("dielectric", 1.5)  # one material per sprite, like the reference
+                d.sprite(sph02, m, mat4_translation((cx, 0.2, cz)))
+    d.sprite(sph1, d.lambertian_rgb((0.4, 0.2, 0.1)), mat4_translation((-4.0, 1.0, 0.0)))
+    d.sprite(sph1, d.mat("metal", d.tex_solid((0.7, 0.6, 0.5)), 0.0), mat4_translation((4.0, 1.0, 0.0)))
+    d.sprite(sph1, d.mat("dielectric", 1.5), mat4_translation((0.0, 1.0, 0.0)))
+    d.camera = ((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), radians(20.0), float(aspect), 10.0, 0.05)
+    return d
+
+
+# ------------------------------------------------------------------ cornell
+def cornell(aspect: float = 1.0) -> SceneDesc:
+    """examples/cornell-box.rs:31-150."""
+    d = SceneDesc(name="cornell-box")
+    red = d.lambertian_rgb((0.65, 0.05, 0.05))
+    white = d.lambertian_rgb((0.73, 0.73, 0.73))
+    green = d.lambertian_rgb((0.12, 0.45, 0.15))
+    light = d.mat("diffuse_light", d.tex_solid((15.0, 15.0, 15.0)))
+    ex, ey = (1.0, 0.0, 0.0), (0.0, 1.0, 0.0)
+
+    def tr(t, deg, axis):
+        return mat4_multiplied(mat4_translation(t), mat4_rotation(radians(deg), axis))
+
+    r555 = d.geom("rectangle", 555.0, 555.0)
+    d.sprite(r555, green, tr((555.0, 555.0 / 2.0, 555.0 / 2.0), -90.0, ey))
+    d.sprite(d.geom("rectangle", 555.0, 555.0), red, tr((0.0, 555.0 / 2.0, 555.0 / 2.0), 90.0, ey))
+    d.sprite(d.geom("rectangle", 130.0, 105.0), light, tr((555.0 / 2.0, 554.0, 555.0 / 2.0), 90.0, ex))
+    d.sprite(d.geom("rectangle", 555.0, 555.0), white, tr((555.0 / 2.0, 0.0, 555.0 / 2.0), -90.0, ex))
+    d.sprite(d.geom("rectangle", 555.0, 555.0), white, tr((555.0 / 2.0, 555.0, 555.0 / 2.0), 90.0, ex))
+    d.sprite(d.geom("rectangle", 555.0, 556.0), white, tr((555.0 / 2.0, 555.0 / 2.0, 555.0), 180.0, ey))
+    d.sprite(d.geom("cube", 165.0, 165.0, 165.0), white, tr((212.5, 82.5, 147.5), -18.0, ey))
+    d.sprite(d.geom("cube", 165.0, 330.0, 165.0), white, tr((347.5, 165.0, 377.5), 15.0, ey))
+    d.camera = ((555.0 / 2.0, 555.0 / 2.0, -800.0), (555.0 / 2.0, 555.0 / 2.0, 0.0), (0.0, 1.0, 0.0), radians(40.0),
+                float(aspect), 10.0, 0.0)
+    return d
+
+
+# ------------------------------------------------------------------ book-two cover
+def earth_texture(w: int = 1024, h: int = 512) -> np.ndarray:
+    """Deterministic procedural stand-in for ./earthmap.jpg (absent upstream, examples/main.rs:266)."""
+    yy, xx = np.mgrid[0:h, 0:w]
+    lat = (yy.astype(np.int64) * 180) // h
+    lon = (xx.astype(np.int64) * 360) // w
+    land = (((lon // 30) + (lat // 20)) % 2 == 0) & (lat > 20) & (lat < 160)
+    img = np.zeros((h, w, 3), dtype=np.uint8)
+    img[..., 0] = np.where(land, 60 + (lat % 64), 20)
+    img[..., 1] = np.where(land, 140 - (lat % 40), 60 + (lon % 50))
+    img[..., 2] = np.where(land, 50, 160 + (lat % 80))
+    ice = (lat <= 12) | (lat >= 168)
+    img[ice] = (235, 240, 245)
+    return img
+
+
+def cover(scene_seed: int = 1, aspect: float = 1.0, with_fog: bool = True) -> SceneDesc:
+    """finalScene() of examples/main.rs:156-330 + camera :49-61."""
+    d = SceneDesc(name="book-two-cover")
+    g = HostRng(scene_seed)
+    ground = d.lambertian_rgb((0.48, 0.83, 0.53))
+    cubes = []
+    for i in range(20):
+        for j in range(20):
+            w = 100.0
+            x0 = -1000.0 + float(i) * w
+            y0 = 0.0
+            z0 = -1000.0 + float(j) * w
+            x1 = x0 + w
+            y1 = g.gen_range(1.0, 101.0)
+            z1 = z0 + w
+            cubes.append(d.sprite(d.geom("cube", x1 - x0, y1 - y0, z1 - z0), ground,
+                                  mat4_translation(((x0 + x1) / 2.0, (y0 + y1) / 2.0, (z0 + z1) / 2.0))))
+    light = d.sprite(d.geom("rectangle", 300.0, 265.0), d.mat("diffuse_light", d.tex_solid((7.0, 7.0, 7.0))),
+                     mat4_multiplied(mat4_translation((273.0, 554.0, 279.5)), mat4_rotation(radians(90.0), (1.0, 0.0, 0.0))))
+    s50 = d.geom("sphere", 50.0)
+    moving = d.sprite(s50, d.lambertian_rgb((0.7, 0.3, 0.1)), mat4_translation((400.0, 400.0, 200.0)))
+    glass = d.sprite(d.geom("sphere", 50.0), d.mat("dielectric", 1.5), mat4_translation((260.0, 150.0, 45.0)))
+    metal = d.sprite(d.geom("sphere", 50.0), d.mat("metal", d.tex_solid((0.8, 0.8, 0.9)), 1.0),
+                     mat4_translation((0.0, 150.0, 145.0)))
+    blue_surface = d.sprite(d.geom("sphere", 70.0), d.mat("dielectric", 1.5), mat4_translation((360.0, 150.0, 145.0)))
+    blue_medium = d.sprite(d.geom("medium", d.geom("sphere", 70.0 - 1e-6), 0.03),
+                           d.mat("isotropic", d.tex_solid((0.2, 0.4, 0.9))), mat4_translation((360.0, 150.0, 145.0)))
+    fog = d.sprite(d.geom("medium", d.geom("sphere", 5000.0), 0.0001), d.mat("isotropic", d.tex_solid((1.0, 1.0, 1.0))),
+                   None) if with_fog else None
+    d.textures.append(("image", earth_texture()))
+    earth = d.sprite(d.geom("sphere", 100.0), d.mat("lambertian", len(d.textures) - 1), mat4_translation((400.0, 200.0, 400.0)))
+    white = d.lambertian_rgb((0.73, 0.73, 0.73))
+    s10 = d.geom("sphere", 10.0)
+    spheres = []
+    for _ in range(1000):
+        x = g.gen_range(0.0, 165.0)
+        y = g.gen_range(0.0, 165.0)
+        z = g.gen_range(0.0, 165.0)
+        spheres.append(d.sprite(s10, white, mat4_translation((x - 100.0, y + 270.0, z + 395.0))))
+    # nesting of examples/main.rs:316-327 (nested BVH nodes have no transform)
+    d.world = [("bvh", cubes), light, moving, glass, metal, blue_surface, blue_medium, earth] + \
+              ([fog] if with_fog else []) + [("bvh", spheres)]
+    d.camera = ((555.0 / 2.0 + 200.0, 550.0 / 2.0, -600.0), (555.0 / 2.0, 555.0 / 2.0, 0.0), (0.0, 1.0, 0.0), radians(40.0),
+                float(aspect), 10.0, 0.0)
+    return d
+
+
+# ------------------------------------------------------------------ product side
+def build_product(desc: SceneDesc, device: int = 0):
+    """Feed a SceneDesc through the C ABI; returns (Scene, Camera)."""
+    import importlib
+    import sys
+    rt = sys.modules.get("ray_tracer_amd") or importlib.import_module("ray_tracer_amd")
+    sc = rt.Scene()
+    for t in desc.textures:
+        if t[0] == "solid":
+            sc.solid(t[1])
+        elif t[0] == "checker":
+            sc.checker(t[1], t[2])
+        elif t[0] == "image":
+            sc.image(t[1])
+        else:
+            raise ValueError(t[0])
+    for m in desc.materials:
+        getattr(sc, m[0])(*m[1:])
+    for gm in desc.geometries:
+        if gm[0] == "medium":
+            sc.constant_medium(gm[1], gm[2])
+        else:
+            getattr(sc, gm[0])(*gm[1:])
+    for (gi, mi, M) in desc.sprites:
+        sc.sprite(gi, mi, M)
+    sc.commit(device)
+    cam = rt.Camera(*desc.camera)
+    return sc, cam

@@ -1,0 +1,110 @@
+// lane_emul.cpp -- TEST HARNESS ONLY (built into tests/_build/liblane_emul.so).
+// Compiles the device lane program (ray-tracer_amd/csrc/rt_lane.h) for the HOST
+// and runs it pixel by pixel over the committed flat scene, so the flattener,
+// the BVH and the lane arithmetic can be diffed against the oracle on a machine
+// without a GPU.  It is not part of librt_mi355x.so and nothing in the product
+// calls it; GPU parity is established separately by the `-m gpu` tests.
+#include "../ray-tracer_amd/csrc/rt_lane.h"
+#include "../ray-tracer_amd/csrc/rt_scene_priv.h"
+#include "../include/rt_mi355x.h"
+
+#include <cstring>
+
+namespace {
+struct ArrayStack {
+    int32_t v[RT_STACK_DEPTH];
+    int sp = 0;
+    int high_water = 0;
+    void reset() { sp = 0; }
+    void push(int32_t x) {
+        v[sp++] = x;
+        if (sp > high_water) high_water = sp;
+    }
+    int32_t pop() { return v[--sp]; }
+    bool empty() const { return sp == 0; }
+};
+
+template <bool G, bool M, bool T, bool LENS>
+void run(const RtLaunch &L, int x0, int y0, int x1, int y1, double *out, double *samples_out, int sx, int sy,
+         unsigned long long *cnt, int *stack_high) {
+    ArrayStack st;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+            rtl::V3 acc = rtl::mk(0, 0, 0);
+            for (int s = 0; s < L.spp; ++s) {
+                rtl::PathState ps;
+                rtl::start_sample<LENS>(L, (uint32_t)x, (uint32_t)y, (uint32_t)s, &ps);
+                for (;;) {
+                    cnt[1]++;
+                    if (rtl::advance_segment<G, M, T>(L, &ps, st, &cnt[2], &cnt[3])) break;
+                }
+                cnt[0]++;
+                cnt[4] += ps.g.draws;
+                acc = acc + ps.Lsum;
+                if (samples_out && x == sx && y == sy) {
+                    samples_out[s * 3 + 0] = ps.Lsum.x;
+                    samples_out[s * 3 + 1] = ps.Lsum.y;
+                    samples_out[s * 3 + 2] = ps.Lsum.z;
+                }
+            }
+            double *o = out + ((size_t)y * L.width + x) * 3;
+            o[0] = acc.x / (double)L.spp;
+            o[1] = acc.y / (double)L.spp;
+            o[2] = acc.z / (double)L.spp;
+        }
+    *stack_high = st.high_water;
+}
+} // namespace
+
+// counters: samples, segments, nodes_visited, prims_tested, rng_draws
+extern "C" int lane_emul_render(rt_scene *s, const rt_camera *cam, int W, int H, int spp, int max_depth, uint64_t seed, int x0,
+                                int y0, int x1, int y1, double *out, double *samples_out, int sx, int sy,
+                                unsigned long long counters[5], int *stack_high) {
+    if (!s || !s->committed) return -1;
+    RtLaunch L;
+    std::memset(&L, 0, sizeof L);
+    L.nodes = s->flat.nodes.data();
+    L.prims = s->flat.prims.data();
+    L.xforms = s->flat.xforms.data();
+    L.materials = s->flat.materials.data();
+    L.textures = s->flat.textures.data();
+    L.image_blob = s->flat.image_blob.data();
+    L.root = s->flat.root;
+    L.n_prims = s->flat.n_leaf_prims;
+    for (int i = 0; i < 3; ++i) {
+        L.cam.eye[i] = cam->eye[i];
+        L.cam.lower_left[i] = cam->lower_left[i];
+        L.cam.horizontal[i] = cam->horizontal[i];
+        L.cam.vertical[i] = cam->vertical[i];
+    }
+    L.cam.lens_radius = cam->lens_radius;
+    L.width = W;
+    L.height = H;
+    L.spp = spp;
+    L.max_depth = max_depth;
+    L.seed_mix = rt_mix64(seed);
+    unsigned long long cnt[5] = {0, 0, 0, 0, 0};
+    int hw = 0;
+    const bool general = (s->flat.feature_mask & (RT_FEAT_GENERAL | RT_FEAT_MEDIUM | RT_FEAT_TEXTURED)) != 0;
+    const bool lens = cam->lens_radius != 0.0;
+    if (max_depth <= 0) {
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) {
+                double *o = out + ((size_t)y * W + x) * 3;
+                o[0] = o[1] = o[2] = 0.0;
+            }
+    } else if (!general) {
+        if (lens)
+            run<false, false, false, true>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
+        else
+            run<false, false, false, false>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
+    } else {
+        if (lens)
+            run<true, true, true, true>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
+        else
+            run<true, true, true, false>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
+    }
+    if (counters) std::memcpy(counters, cnt, sizeof cnt);
+    if (stack_high) *stack_high = hw;
+    return 0;
+}

@@ -1,0 +1,30 @@
+"""ctypes binding of tests/_build/liblane_emul.so (host compile of the device lane program; tests only)."""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+# the product library must be loaded first: liblane_emul only reads the committed flat scene
+_LIB = C.CDLL(str(ROOT / "tests" / "_build" / "liblane_emul.so"))
+_DP = C.POINTER(C.c_double)
+_LIB.lane_emul_render.restype = C.c_int
+_LIB.lane_emul_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, _DP, _DP, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]
+
+
+def render(scene, cam, W, H, spp, max_depth, seed=1, region=None, sample_pixel=None):
+    """-> image (H,W,3), counters dict, stack high-water mark, [per-sample radiance of sample_pixel]."""
+    x0, y0, x1, y1 = region if region else (0, 0, W, H)
+    out = np.zeros((H, W, 3))
+    cnt = (C.c_ulonglong * 5)()
+    hw = C.c_int()
+    samples = np.zeros((spp, 3)) if sample_pixel else None
+    sx, sy = sample_pixel if sample_pixel else (-1, -1)
+    rc = _LIB.lane_emul_render(scene._h, C.addressof(cam.c), W, H, spp, max_depth, seed, x0, y0, x1, y1,
+                               out.ctypes.data_as(_DP), samples.ctypes.data_as(_DP) if sample_pixel else None, sx, sy, cnt,
+                               C.byref(hw))
+    assert rc == 0
+    names = ("samples", "segments", "nodes_visited", "prims_tested", "rng_draws")
+    res = (out, dict(zip(names, [int(c) for c in cnt])), hw.value)
+    return res + (samples,) if sample_pixel else res
