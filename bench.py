@@ -95,7 +95,6 @@ def main():
     gathered = torch.zeros(world * pad_tiles * 64 * 3, dtype=torch.float64, device=dev) if rank == 0 else None
     image = torch.zeros(H * W * 3, dtype=torch.float64, device=dev) if rank == 0 else None
     host_image = torch.zeros(H * W * 3, dtype=torch.float64).pin_memory() if rank == 0 else None
-    kernel_ms = []
 
     def step():
         stream = torch.cuda.current_stream().cuda_stream
@@ -119,7 +118,6 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
-        kernel_ms.append(None)  # filled after the sync below (events are per launch; read the last one)
     sync()
     dt = time.perf_counter() - t0
     last_kernel_ms = sc.last_kernel_ms()
@@ -163,7 +161,8 @@ def main():
                          "kernel": "render_kernel", "kernel_ms": kernel_avg_ms, "algorithmic_bytes_per_sample": bytes_per_sample,
                          "segments_per_sample": cnt["segments"] / ns, "nodes_per_sample": cnt["nodes_visited"] / ns,
                          "prims_per_sample": cnt["prims_tested"] / ns,
-                         "simd_lane_utilisation": cnt["lane_iterations"] / max(1, 64 * cnt["wave_iterations"])},
+                         "simd_utilisation": {b: cnt[b + "_lane"] / max(1, 64 * cnt[b + "_wave"]) for b in ("node", "leaf", "shade")},
+                         "block_executions_per_sample": {b: cnt[b + "_wave"] * 64 / ns for b in ("node", "leaf", "shade")}},
             "wall_s": dt, "last_kernel_ms": last_kernel_ms,
         }
         if not a.no_cpu_baseline and world == 1:

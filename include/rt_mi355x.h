@@ -140,7 +140,10 @@ typedef struct rt_render_params {
 #define RT_FLAG_COUNTERS 1u       /* also accumulate rt_counters (slower build of the kernel) */
 
 typedef struct rt_counters {
-    uint64_t samples, segments, nodes_visited, prims_tested, rng_draws, wave_iterations, lane_iterations;
+    uint64_t samples, segments, nodes_visited, prims_tested, rng_draws;
+    /* executions of each block of the wave-vote loop and the lanes active in them:
+     * lane / (64 * wave) is the SIMD utilisation of that block */
+    uint64_t node_wave, node_lane, leaf_wave, leaf_lane, shade_wave, shade_lane;
 } rt_counters;
 
 /* Render into host memory: out_rgb[(y*W + x)*3 + c].  With shard_count > 1 only
@@ -172,8 +175,9 @@ int rt_write_ppm_p3(const char *path, const double *rgb, int width, int height);
 
 /* ---- inspection of the committed flat scene (tests, algorithmic-byte accounting) ---- */
 typedef struct rt_scene_info {
-    int n_prims;        /* leaves of the acceleration structure */
+    int n_prims;        /* sprites that can be hit (hoisted + BVH leaves) */
     int n_child_prims;  /* faces inside cube instances */
+    int n_hoisted;      /* scene-spanning prims tested directly for every segment */
     int n_nodes;
     int max_depth;      /* deepest leaf */
     int n_materials, n_textures, n_xforms;
@@ -182,8 +186,9 @@ typedef struct rt_scene_info {
     size_t device_bytes;                        /* total resident bytes after upload */
 } rt_scene_info;
 int rt_scene_get_info(const rt_scene *, rt_scene_info *out);
-/* copy of the flat BVH: nodes as 16 doubles each {lo0[3],hi0[3],lo1[3],hi1[3],child0,child1,-,-};
- * child >= 0 inner node index, child < 0 leaf ~prim */
+/* copy of the flat BVH: 28 doubles per node
+ * {lo0[3],hi0[3],lo1[3],hi1[3], child0,child1, culllo0[3],cullhi0[3],culllo1[3],cullhi1[3], -,-};
+ * child >= 0 inner node index, child < 0 leaf ~prim; cull* = the binary32 culling boxes */
 int rt_scene_copy_nodes(const rt_scene *, double *out, int max_nodes);
 /* world-space AABB of prim i: {lo[3], hi[3]} */
 int rt_scene_prim_bounds(const rt_scene *, int prim, double out[6]);

@@ -46,14 +46,15 @@ class rt_render_params(C.Structure):
 
 class rt_counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "segments", "nodes_visited", "prims_tested", "rng_draws",
-                                            "wave_iterations", "lane_iterations")]
+                                            "node_wave", "node_lane", "leaf_wave", "leaf_lane", "shade_wave", "shade_lane")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
 class rt_scene_info(C.Structure):
-    _fields_ = [("n_prims", C.c_int), ("n_child_prims", C.c_int), ("n_nodes", C.c_int), ("max_depth", C.c_int),
+    _fields_ = [("n_prims", C.c_int), ("n_child_prims", C.c_int), ("n_hoisted", C.c_int), ("n_nodes", C.c_int),
+                ("max_depth", C.c_int),
                 ("n_materials", C.c_int), ("n_textures", C.c_int), ("n_xforms", C.c_int), ("node_bytes", C.c_int),
                 ("prim_bytes", C.c_int), ("material_bytes", C.c_int), ("feature_mask", C.c_uint),
                 ("device_bytes", C.c_size_t)]
@@ -260,7 +261,7 @@ class Scene:
 
     def nodes(self) -> np.ndarray:
         n = self.info()["n_nodes"]
-        out = np.zeros((n, 16))
+        out = np.zeros((n, 28))
         _check(lib().rt_scene_copy_nodes(self._h, _dp(out), n))
         return out
 

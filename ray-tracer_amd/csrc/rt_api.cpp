@@ -11,14 +11,19 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <string>
 #include <vector>
 
-extern "C" int rt_launch_render(const RtLaunch *L, unsigned features, int lens, int count, void *stream);
+extern "C" int rt_launch_render(const RtLaunch *L, unsigned features, int lens, int count, int blocks, void *stream);
+extern "C" int rt_launch_reduce(const double *samples, double *tiles, int n_owned_tiles, int s_count, int first_pass, int last_pass,
+                                int spp, int width, int height, int shard_index, int shard_count, void *stream);
+extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int *blocks_per_cu, int *n_cu);
 extern "C" int rt_launch_unpack(const double *gathered, int tiles_per_shard, int shard_count, int width, int height,
                                 double *image, void *stream);
 extern "C" int rt_launch_probe_math(const double *a, const double *b, int n, double *out_sqrt, double *out_div, void *stream);
@@ -181,15 +186,15 @@ int rt_scene_commit(rt_scene *s, int device) {
         s->device = device;
         size_t total = 0;
         if ((rc = upload(s->flat.nodes, &s->d_nodes, &total))) return rc;
-        if ((rc = upload(s->flat.prims, &s->d_prims, &total))) return rc;
+        if ((rc = upload(s->flat.prim_meta, &s->d_prim_meta, &total))) return rc;
+        if ((rc = upload(s->flat.prim_geo, &s->d_prim_geo, &total))) return rc;
+        if ((rc = upload(s->flat.prim_extra, &s->d_prim_extra, &total))) return rc;
         if ((rc = upload(s->flat.xforms, &s->d_xforms, &total))) return rc;
         if ((rc = upload(s->flat.materials, &s->d_materials, &total))) return rc;
         if ((rc = upload(s->flat.textures, &s->d_textures, &total))) return rc;
         if ((rc = upload(s->flat.image_blob, &s->d_blob, &total))) return rc;
         s->device_bytes = total;
-        HIP_TRY(hipEventCreate(&s->ev0));
-        HIP_TRY(hipEventCreate(&s->ev1));
-        s->have_events = true;
+        HIP_TRY(hipMalloc(&s->d_job_counter, 256));
     }
     s->committed = true;
     return RT_OK;
@@ -232,16 +237,18 @@ static int check_params(const rt_scene *s, const rt_camera *cam, const rt_render
     return RT_OK;
 }
 
-static void fill_launch(const rt_scene *s, const rt_camera *cam, const rt_render_params *p, int n_owned, double *d_out,
-                        void *d_counters, RtLaunch *L) {
+static void fill_launch(const rt_scene *s, const rt_camera *cam, const rt_render_params *p, int n_owned, RtLaunch *L) {
     std::memset(L, 0, sizeof *L);
     L->nodes = (const RtNode *)s->d_nodes;
-    L->prims = (const RtPrim *)s->d_prims;
+    L->prim_meta = (const RtPrimMeta *)s->d_prim_meta;
+    L->prim_geo = (const RtPrimGeo *)s->d_prim_geo;
+    L->prim_extra = (const RtPrimExtra *)s->d_prim_extra;
     L->xforms = (const RtXform *)s->d_xforms;
     L->materials = (const RtMaterial *)s->d_materials;
     L->textures = (const RtTexture *)s->d_textures;
     L->image_blob = (const uint8_t *)s->d_blob;
     L->root = s->flat.root;
+    L->n_hoisted = s->flat.n_hoisted;
     L->n_prims = s->flat.n_leaf_prims;
     for (int i = 0; i < 3; ++i) {
         L->cam.eye[i] = cam->eye[i];
@@ -260,8 +267,7 @@ static void fill_launch(const rt_scene *s, const rt_camera *cam, const rt_render
     L->shard_index = p->shard_index;
     L->shard_count = p->shard_count;
     L->n_owned_tiles = n_owned;
-    L->out = d_out;
-    L->counters = (RtCounters *)d_counters;
+    L->job_counter = (unsigned int *)s->d_job_counter;
 }
 
 static unsigned kernel_features(const rt_scene *s) {
@@ -270,6 +276,13 @@ static unsigned kernel_features(const rt_scene *s) {
     if (s->flat.feature_mask & RT_FEAT_MEDIUM) f |= 2u;
     if (s->flat.feature_mask & RT_FEAT_TEXTURED) f |= 4u;
     return f;
+}
+
+// bytes of per-sample workspace a render may use; more samples are rendered in several passes
+static size_t sample_workspace_cap() {
+    const char *e = std::getenv("RT_SAMPLE_WORKSPACE_MB");
+    if (e && *e) return (size_t)std::strtoull(e, nullptr, 10) << 20;
+    return (size_t)24 << 30; // 24 GiB of the 288 GB
 }
 
 int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_render_params *p, void *d_tiles_out, void *d_counters,
@@ -281,19 +294,67 @@ int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_render_pa
     if (n_owned < 0) return n_owned;
     hipStream_t st = (hipStream_t)stream;
     std::lock_guard<std::mutex> lock(s->mu);
-    HIP_TRY(hipEventRecord(s->ev0, st));
-    if (p->max_depth == 0 || n_owned == 0) {
-        // color(ray, world, 0) is black before anything is traced (src/render.rs:6-8)
-        if (n_owned) HIP_TRY(hipMemsetAsync(d_tiles_out, 0, (size_t)n_owned * RT_TILE_PIXELS * 3 * sizeof(double), st));
-    } else {
-        RtLaunch L;
-        fill_launch(s, cam, p, n_owned, (double *)d_tiles_out, d_counters, &L);
-        const bool count = (p->flags & RT_FLAG_COUNTERS) && d_counters;
-        int rc = rt_launch_render(&L, kernel_features(s), cam->lens_radius != 0.0, count, stream);
-        if (rc != 0) return hip_fail((hipError_t)rc, "render_kernel launch");
-    }
-    HIP_TRY(hipEventRecord(s->ev1, st));
+    s->events_used = 0;
     s->timed = true;
+    if (n_owned == 0) return RT_OK;
+    const size_t tile_doubles = (size_t)n_owned * RT_TILE_PIXELS * 3;
+    if (p->max_depth == 0) {
+        // color(ray, world, 0) is black before anything is traced (src/render.rs:6-8)
+        HIP_TRY(hipMemsetAsync(d_tiles_out, 0, tile_doubles * sizeof(double), st));
+        return RT_OK;
+    }
+    // pass size: as many samples per pixel as the workspace cap allows
+    const size_t bytes_per_spp = tile_doubles * sizeof(double);
+    int chunk = (int)std::min<size_t>((size_t)p->spp, std::max<size_t>(1, sample_workspace_cap() / bytes_per_spp));
+    // slot indices are 32-bit
+    chunk = (int)std::min<size_t>((size_t)chunk, (size_t)0xFFFFFFFFu / ((size_t)n_owned * RT_TILE_PIXELS));
+    if (chunk < 1) return fail(RT_ERR_INVALID, "image too large for one shard");
+    const size_t need = bytes_per_spp * (size_t)chunk;
+    if (need > s->samples_bytes) {
+        if (s->d_samples) {
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipFree(s->d_samples));
+            s->d_samples = nullptr;
+            s->samples_bytes = 0;
+        }
+        HIP_TRY(hipMalloc(&s->d_samples, need));
+        s->samples_bytes = need;
+    }
+    const bool count = (p->flags & RT_FLAG_COUNTERS) && d_counters;
+    const unsigned feat = kernel_features(s);
+    const int lens = cam->lens_radius != 0.0;
+    int per_cu = 0, n_cu = 0;
+    int rc = rt_persistent_blocks(feat, lens, count, &per_cu, &n_cu);
+    if (rc != 0) return hip_fail((hipError_t)rc, "occupancy query");
+    if (per_cu < 1) per_cu = 1;
+    RtLaunch L;
+    fill_launch(s, cam, p, n_owned, &L);
+    L.samples = (double *)s->d_samples;
+    L.counters = count ? (RtCounters *)d_counters : nullptr;
+    const int n_pass = (p->spp + chunk - 1) / chunk;
+    while ((int)s->events.size() < 2 * n_pass) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        s->events.push_back(e);
+    }
+    for (int pass = 0; pass < n_pass; ++pass) {
+        L.s0 = pass * chunk;
+        L.s_count = std::min(chunk, p->spp - L.s0);
+        L.jobs_per_tile = (L.s_count + RT_JOB_SPP - 1) / RT_JOB_SPP;
+        const long long n_jobs = (long long)L.jobs_per_tile * n_owned;
+        if (n_jobs > 0x7FFFFFFFll) return fail(RT_ERR_INVALID, "too many jobs in one pass");
+        L.n_jobs = (int)n_jobs;
+        const int blocks = (int)std::min<long long>((long long)per_cu * n_cu, (n_jobs + 3) / 4 > 0 ? (n_jobs + 3) / 4 : 1);
+        HIP_TRY(hipMemsetAsync(s->d_job_counter, 0, sizeof(unsigned int), st));
+        HIP_TRY(hipEventRecord(s->events[(size_t)(2 * pass)], st));
+        rc = rt_launch_render(&L, feat, lens, count, blocks, stream);
+        if (rc != 0) return hip_fail((hipError_t)rc, "render_kernel launch");
+        HIP_TRY(hipEventRecord(s->events[(size_t)(2 * pass + 1)], st));
+        s->events_used = 2 * (pass + 1);
+        rc = rt_launch_reduce(L.samples, (double *)d_tiles_out, n_owned, L.s_count, pass == 0, pass == n_pass - 1, p->spp, p->width,
+                              p->height, p->shard_index, p->shard_count, stream);
+        if (rc != 0) return hip_fail((hipError_t)rc, "reduce_kernel launch");
+    }
     return RT_OK;
 }
 
@@ -302,8 +363,14 @@ int rt_last_kernel_ms(rt_scene *s, float *ms) {
     std::lock_guard<std::mutex> lock(s->mu);
     if (!s->timed) return fail(RT_ERR_STATE, "no render has been launched on this scene");
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipEventSynchronize(s->ev1));
-    HIP_TRY(hipEventElapsedTime(ms, s->ev0, s->ev1));
+    float total = 0.0f;
+    for (int i = 0; i + 1 < s->events_used; i += 2) {
+        float t = 0.0f;
+        HIP_TRY(hipEventSynchronize(s->events[(size_t)i + 1]));
+        HIP_TRY(hipEventElapsedTime(&t, s->events[(size_t)i], s->events[(size_t)i + 1]));
+        total += t;
+    }
+    *ms = total;
     return RT_OK;
 }
 
@@ -349,8 +416,12 @@ int rt_render(rt_scene *s, const rt_camera *cam, const rt_render_params *p, doub
             counters->nodes_visited = c.nodes_visited;
             counters->prims_tested = c.prims_tested;
             counters->rng_draws = c.rng_draws;
-            counters->wave_iterations = c.wave_iterations;
-            counters->lane_iterations = c.lane_iterations;
+            counters->node_wave = c.node_wave;
+            counters->node_lane = c.node_lane;
+            counters->leaf_wave = c.leaf_wave;
+            counters->leaf_lane = c.leaf_lane;
+            counters->shade_wave = c.shade_wave;
+            counters->shade_lane = c.shade_lane;
         }
     }
     (void)hipFree(d_out);
@@ -408,14 +479,15 @@ int rt_scene_get_info(const rt_scene *s, rt_scene_info *out) {
     if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
     std::memset(out, 0, sizeof *out);
     out->n_prims = s->flat.n_leaf_prims;
-    out->n_child_prims = (int)s->flat.prims.size() - s->flat.n_leaf_prims;
+    out->n_child_prims = (int)s->flat.prim_meta.size() - s->flat.n_leaf_prims;
+    out->n_hoisted = s->flat.n_hoisted;
     out->n_nodes = (int)s->flat.nodes.size();
     out->max_depth = s->flat.max_depth;
     out->n_materials = (int)s->flat.materials.size();
     out->n_textures = (int)s->flat.textures.size();
     out->n_xforms = (int)s->flat.xforms.size();
     out->node_bytes = (int)sizeof(RtNode);
-    out->prim_bytes = (int)sizeof(RtPrim);
+    out->prim_bytes = (int)sizeof(RtPrimGeo);
     out->material_bytes = (int)sizeof(RtMaterial);
     out->feature_mask = s->flat.feature_mask;
     out->device_bytes = s->device_bytes;
@@ -425,19 +497,26 @@ int rt_scene_get_info(const rt_scene *s, rt_scene_info *out) {
 int rt_scene_copy_nodes(const rt_scene *s, double *out, int max_nodes) {
     if (!s || !out) return fail(RT_ERR_INVALID, "null argument");
     if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
-    const int n = (int)s->flat.nodes.size();
+    const int n = (int)s->flat.host_nodes.size();
     for (int i = 0; i < n && i < max_nodes; ++i) {
-        const RtNode &nd = s->flat.nodes[(size_t)i];
-        double *o = out + (size_t)i * 16;
-        for (int k = 0; k < 3; ++k) {
-            o[k] = nd.lo0[k];
-            o[3 + k] = nd.hi0[k];
-            o[6 + k] = nd.lo1[k];
-            o[9 + k] = nd.hi1[k];
+        const rt::HostNode &nd = s->flat.host_nodes[(size_t)i];
+        const RtNode &cn = s->flat.nodes[(size_t)i];
+        double *o = out + (size_t)i * 28;
+        for (int c = 0; c < 2; ++c) {
+            for (int k = 0; k < 3; ++k) {
+                o[c * 6 + k] = nd.box[c].lo[k];
+                o[c * 6 + 3 + k] = nd.box[c].hi[k];
+            }
+            o[12 + c] = (double)nd.child[c];
+            // the binary32 culling box actually traversed
+            o[14 + c * 6 + 0] = cn.lo_x[c];
+            o[14 + c * 6 + 1] = cn.lo_y[c];
+            o[14 + c * 6 + 2] = cn.lo_z[c];
+            o[14 + c * 6 + 3] = cn.hi_x[c];
+            o[14 + c * 6 + 4] = cn.hi_y[c];
+            o[14 + c * 6 + 5] = cn.hi_z[c];
         }
-        o[12] = (double)nd.child0;
-        o[13] = (double)nd.child1;
-        o[14] = o[15] = 0.0;
+        o[26] = o[27] = 0.0;
     }
     return n;
 }

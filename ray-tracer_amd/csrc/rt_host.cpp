@@ -253,6 +253,26 @@ void cube_faces(double width, double height, double depth, CubeFace f[6]) {
 
 } // namespace
 
+// binary32 culling box: round outward, then pad by 2^-21 of the coordinate
+// magnitude / extent.  Together with the per-ray pad of the kernel (2^-21 |o|) this
+// exceeds the worst-case displacement between the binary64 ray and its binary32
+// image at the box (<= 2^-24 (|o| + t|d|) per axis, |o + t d| <= |box|) by > 2x.
+void cull_box(const Aabb &b, float lo[3], float hi[3]) {
+    for (int i = 0; i < 3; ++i) {
+        float l = (float)b.lo[i], h = (float)b.hi[i];
+        if ((double)l > b.lo[i]) l = std::nextafterf(l, -std::numeric_limits<float>::infinity());
+        if ((double)h < b.hi[i]) h = std::nextafterf(h, std::numeric_limits<float>::infinity());
+        if (std::isfinite(l) && std::isfinite(h)) {
+            const float scale = std::fmax(std::fmax(std::fabs(l), std::fabs(h)), h - l);
+            const float e = scale * 0x1p-21f + 1e-30f;
+            l -= e;
+            h += e;
+        }
+        lo[i] = l;
+        hi[i] = h;
+    }
+}
+
 int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
     FlatScene fs;
 
@@ -293,12 +313,16 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
         fs.materials.push_back(d);
     }
 
-    // sprites -> leaf prims
-    struct PendingGroup {
-        size_t prim;
+    // sprites -> leaf prims (in creation order first; hoisted ones are moved to the front below)
+    struct Leaf {
+        RtPrimMeta meta;
+        RtPrimGeo geo;
+        RtPrimExtra extra;
+        Aabb bound;
+        bool is_group;
         CubeFace faces[6];
     };
-    std::vector<PendingGroup> groups;
+    std::vector<Leaf> leaves;
     uint32_t medium_slots = 0;
     for (const SpriteIR &s : ir.sprites) {
         if (s.geometry < 0) continue; // geometry None: never hit (src/sprite.rs:95,136)
@@ -307,46 +331,46 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
         if (g.kind == GEO_MEDIUM) slot = (medium_slots++) & 0x3FFu; // slots count sprites in creation order
         double Minv[16];
         if (!mat4_inversed(s.M, Minv)) continue; // det == 0: unhittable (src/sprite.rs:131-134)
-        RtPrim p{};
+        Leaf lf{};
+        RtPrimMeta &p = lf.meta;
+        double *geo = lf.geo.g;
         p.material = s.material < 0 ? RT_NO_MATERIAL : (uint32_t)s.material;
         const bool trans = is_pure_translation(s.M);
-        Aabb local;
+        Aabb local{};
         switch (g.kind) {
         case GEO_SPHERE:
             local = sphere_bound(g.p[0]);
             if (trans) {
                 p.kind = RT_PRIM_SPHERE_T;
-                p.g[0] = s.M[12];
-                p.g[1] = s.M[13];
-                p.g[2] = s.M[14];
-                p.g[3] = g.p[0];
+                geo[0] = s.M[12];
+                geo[1] = s.M[13];
+                geo[2] = s.M[14];
+                geo[3] = g.p[0];
                 fs.feature_mask |= RT_FEAT_SPHERE_T;
             } else {
                 p.kind = RT_PRIM_SPHERE_M;
-                p.g[0] = g.p[0];
+                geo[0] = g.p[0];
                 fs.feature_mask |= RT_FEAT_GENERAL;
             }
             break;
         case GEO_RECTANGLE:
             local = rect_bound(g.p[0], g.p[1]);
             p.kind = RT_PRIM_RECT_M;
-            p.g[0] = g.p[0];
-            p.g[1] = g.p[1];
+            geo[0] = g.p[0];
+            geo[1] = g.p[1];
             fs.feature_mask |= RT_FEAT_GENERAL;
             break;
         case GEO_CUBE: {
-            PendingGroup pg;
-            pg.prim = fs.prims.size();
-            cube_faces(g.p[0], g.p[1], g.p[2], pg.faces);
+            lf.is_group = true;
+            cube_faces(g.p[0], g.p[1], g.p[2], lf.faces);
             bool first = true;
-            for (const CubeFace &f : pg.faces) {
+            for (const CubeFace &f : lf.faces) {
                 Aabb fb = transformed_bound(rect_bound(f.w, f.h), f.M);
                 local = first ? fb : merged(local, fb);
                 first = false;
             }
-            groups.push_back(pg);
             p.kind = RT_PRIM_GROUP_M;
-            p.g[0] = 6.0;
+            geo[0] = 6.0;
             fs.feature_mask |= RT_FEAT_GENERAL;
             break;
         }
@@ -356,15 +380,15 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
             p.aux = slot;
             if (trans) {
                 p.kind = RT_PRIM_MEDIUM_T;
-                p.g[0] = s.M[12];
-                p.g[1] = s.M[13];
-                p.g[2] = s.M[14];
-                p.g[3] = b.p[0];
-                p.g2[0] = g.p[0];
+                geo[0] = s.M[12];
+                geo[1] = s.M[13];
+                geo[2] = s.M[14];
+                geo[3] = b.p[0];
+                lf.extra.e[0] = g.p[0];
             } else {
                 p.kind = RT_PRIM_MEDIUM_M;
-                p.g[0] = b.p[0];
-                p.g[1] = g.p[0];
+                geo[0] = b.p[0];
+                geo[1] = g.p[0];
             }
             fs.feature_mask |= RT_FEAT_MEDIUM;
             break;
@@ -376,40 +400,109 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
             p.xform = (uint32_t)fs.xforms.size();
             fs.xforms.push_back(x);
         }
-        Aabb wb = transformed_bound(local, s.M);
-        pad(&wb);
-        fs.prims.push_back(p);
-        fs.prim_bounds.push_back(wb);
+        lf.bound = transformed_bound(local, s.M);
+        pad(&lf.bound);
+        leaves.push_back(lf);
     }
-    fs.n_leaf_prims = (int)fs.prims.size();
-    if (fs.n_leaf_prims == 0) {
+    if (leaves.empty()) {
         if (err) *err = "empty scene: BoundingVolumeHierarchyNode::new(vec![]) is None (src/optimize.rs:367-370)";
         return RT_ERR_EMPTY;
     }
+    if (leaves.size() > RT_REF_MAX) {
+        if (err) *err = "more than 32767 sprites: outside the 16-bit node references of this build";
+        return RT_ERR_UNSUPPORTED;
+    }
+
+    // hoist scene-spanning prims (book-one's sky and ground spheres, main.rs's fog): their
+    // boxes make every ancestor an always-hit, so they are tested up front for each
+    // segment and give the traversal an early upper bound instead.
+    auto area = [](const Aabb &b) {
+        const double dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+        return 2.0 * (dx * dy + dy * dz + dz * dx);
+    };
+    Aabb root = leaves[0].bound;
+    for (const Leaf &l : leaves) root = merged(root, l.bound);
+    std::vector<size_t> order(leaves.size());
+    std::iota(order.begin(), order.end(), (size_t)0);
+    std::vector<size_t> hoist;
+    {
+        std::vector<size_t> by_area = order;
+        std::stable_sort(by_area.begin(), by_area.end(), [&](size_t a, size_t b) { return area(leaves[a].bound) > area(leaves[b].bound); });
+        for (size_t i : by_area) {
+            if ((int)hoist.size() >= RT_MAX_HOISTED) break;
+            if (!(area(leaves[i].bound) >= 0.1 * area(root))) break;
+            hoist.push_back(i);
+        }
+        std::sort(hoist.begin(), hoist.end());
+    }
+    std::vector<size_t> final_order = hoist;
+    for (size_t i : order)
+        if (!std::binary_search(hoist.begin(), hoist.end(), i)) final_order.push_back(i);
+    fs.n_hoisted = (int)hoist.size();
+    for (size_t i : final_order) {
+        fs.prim_meta.push_back(leaves[i].meta);
+        fs.prim_geo.push_back(leaves[i].geo);
+        fs.prim_extra.push_back(leaves[i].extra);
+        fs.prim_bounds.push_back(leaves[i].bound);
+    }
+    fs.n_leaf_prims = (int)fs.prim_meta.size();
+
     // group children (never BVH leaves): TransformedGeometry<Rectangle> records
-    for (const PendingGroup &pg : groups) {
-        fs.prims[pg.prim].aux = (uint32_t)fs.prims.size();
+    for (size_t k = 0; k < final_order.size(); ++k) {
+        const Leaf &lf = leaves[final_order[k]];
+        if (!lf.is_group) continue;
+        fs.prim_meta[k].aux = (uint32_t)fs.prim_meta.size();
         int kept = 0;
-        for (const CubeFace &f : pg.faces) {
+        for (const CubeFace &f : lf.faces) {
             double Minv[16];
             if (!mat4_inversed(f.M, Minv)) continue;
-            RtPrim c{};
+            RtPrimMeta c{};
             c.kind = RT_PRIM_RECT_M;
             c.material = RT_NO_MATERIAL;
-            c.g[0] = f.w;
-            c.g[1] = f.h;
+            RtPrimGeo cg{};
+            cg.g[0] = f.w;
+            cg.g[1] = f.h;
             RtXform x;
             make_xform(f.M, Minv, &x);
             c.xform = (uint32_t)fs.xforms.size();
             fs.xforms.push_back(x);
-            fs.prims.push_back(c);
+            fs.prim_meta.push_back(c);
+            fs.prim_geo.push_back(cg);
+            fs.prim_extra.push_back(RtPrimExtra{});
             fs.prim_bounds.push_back(Aabb{{0, 0, 0}, {0, 0, 0}});
             ++kept;
         }
-        fs.prims[pg.prim].g[0] = (double)kept;
+        fs.prim_geo[k].g[0] = (double)kept;
     }
 
-    build_bvh(fs.prim_bounds, fs.n_leaf_prims, &fs.nodes, &fs.root, &fs.max_depth);
+    // BVH over the non-hoisted leaves
+    if (fs.n_hoisted < fs.n_leaf_prims) {
+        const int32_t r = build_bvh(fs.prim_bounds, fs.n_hoisted, fs.n_leaf_prims, &fs.host_nodes, &fs.max_depth);
+        if (fs.host_nodes.size() > RT_REF_MAX) {
+            if (err) *err = "BVH has more than 32767 nodes: outside the 16-bit node references of this build";
+            return RT_ERR_UNSUPPORTED;
+        }
+        auto ref16 = [](int32_t c) { return c >= 0 ? (uint32_t)c : (RT_REF_LEAF | (uint32_t)(~c)); };
+        fs.root = ref16(r);
+        for (const HostNode &h : fs.host_nodes) {
+            RtNode n{};
+            for (int c = 0; c < 2; ++c) {
+                float lo[3], hi[3];
+                cull_box(h.box[c], lo, hi);
+                n.lo_x[c] = lo[0];
+                n.lo_y[c] = lo[1];
+                n.lo_z[c] = lo[2];
+                n.hi_x[c] = hi[0];
+                n.hi_y[c] = hi[1];
+                n.hi_z[c] = hi[2];
+                n.child[c] = ref16(h.child[c]);
+            }
+            fs.nodes.push_back(n);
+        }
+    } else {
+        fs.root = RT_CUR_DONE;
+        fs.max_depth = 0;
+    }
     *out = std::move(fs);
     return RT_OK;
 }
@@ -419,7 +512,7 @@ namespace {
 
 struct Builder {
     const std::vector<Aabb> &bounds;
-    std::vector<RtNode> &nodes;
+    std::vector<HostNode> &nodes;
     int max_depth = 0;
 
     static double area(const Aabb &b) {
@@ -486,47 +579,26 @@ struct Builder {
         Aabb lb, rb;
         const int32_t c0 = build(std::move(left), depth + 1, budget - 1, &lb);
         const int32_t c1 = build(std::move(right), depth + 1, budget - 1, &rb);
-        RtNode &nd = nodes[(size_t)me];
-        std::memset(&nd, 0, sizeof nd);
-        for (int i = 0; i < 3; ++i) {
-            nd.lo0[i] = lb.lo[i];
-            nd.hi0[i] = lb.hi[i];
-            nd.lo1[i] = rb.lo[i];
-            nd.hi1[i] = rb.hi[i];
-        }
-        nd.child0 = c0;
-        nd.child1 = c1;
+        HostNode &nd = nodes[(size_t)me];
+        nd.box[0] = lb;
+        nd.box[1] = rb;
+        nd.child[0] = c0;
+        nd.child[1] = c1;
         return me;
     }
 };
 
 } // namespace
 
-void build_bvh(const std::vector<Aabb> &bounds, int n, std::vector<RtNode> *nodes, int32_t *root, int *max_depth) {
+int32_t build_bvh(const std::vector<Aabb> &bounds, int first, int n, std::vector<HostNode> *nodes, int *max_depth) {
     nodes->clear();
-    std::vector<int> ids((size_t)n);
-    std::iota(ids.begin(), ids.end(), 0);
+    std::vector<int> ids;
+    for (int i = first; i < n; ++i) ids.push_back(i);
     Builder b{bounds, *nodes};
     Aabb box;
-    if (n == 1) {
-        // single primitive: one node whose second child is an empty box
-        RtNode nd;
-        std::memset(&nd, 0, sizeof nd);
-        for (int i = 0; i < 3; ++i) {
-            nd.lo0[i] = bounds[0].lo[i];
-            nd.hi0[i] = bounds[0].hi[i];
-            nd.lo1[i] = kInf;
-            nd.hi1[i] = -kInf;
-        }
-        nd.child0 = ~0;
-        nd.child1 = ~0;
-        nodes->push_back(nd);
-        *root = 0;
-        *max_depth = 1;
-        return;
-    }
-    *root = b.build(std::move(ids), 0, RT_STACK_DEPTH - 1, &box);
+    const int32_t root = b.build(std::move(ids), 0, RT_STACK_DEPTH - 1, &box);
     *max_depth = b.max_depth;
+    return root; // a single prim yields a leaf reference and no nodes
 }
 
 } // namespace rt

@@ -48,15 +48,27 @@ struct SpriteIR {
     double M[16];
 };
 
+// host-side BVH node in binary64 (inspection, tests); RtNode is derived from it
+struct HostNode {
+    Aabb box[2];
+    int32_t child[2]; // >= 0 inner node index, < 0 leaf: prim = ~child
+};
+
 struct FlatScene {
+    std::vector<HostNode> host_nodes;
     std::vector<RtNode> nodes;
-    std::vector<RtPrim> prims; // [0, n_leaf_prims) are BVH leaves, the rest are group children
+    // prims [0, n_hoisted) are scene-spanning and tested directly; [n_hoisted, n_leaf_prims)
+    // are BVH leaves; the rest are group children
+    std::vector<RtPrimMeta> prim_meta;
+    std::vector<RtPrimGeo> prim_geo;
+    std::vector<RtPrimExtra> prim_extra;
     std::vector<Aabb> prim_bounds;
+    int n_hoisted = 0;
     std::vector<RtXform> xforms;
     std::vector<RtMaterial> materials;
     std::vector<RtTexture> textures;
     std::vector<uint8_t> image_blob;
-    int32_t root = 0;
+    uint32_t root = RT_CUR_DONE; // 16-bit reference (RT_REF_*) or RT_CUR_DONE if the BVH is empty
     int n_leaf_prims = 0;
     int max_depth = 0;
     unsigned feature_mask = 0;
@@ -72,8 +84,11 @@ struct SceneIR {
 // Flatten + build.  Returns 0 or an RT_ERR_* code with `err` filled.
 int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err);
 
-// SAH BVH over prim_bounds[0..n); fills nodes/root/max_depth.  Depth <= RT_STACK_DEPTH.
-void build_bvh(const std::vector<Aabb> &bounds, int n, std::vector<RtNode> *nodes, int32_t *root, int *max_depth);
+// SAH BVH over prim_bounds[first..n); fills nodes, returns the root reference
+// (>= 0 node index, < 0 leaf ~prim).  Depth <= RT_STACK_DEPTH.
+int32_t build_bvh(const std::vector<Aabb> &bounds, int first, int n, std::vector<HostNode> *nodes, int *max_depth);
+// binary32 culling box of a binary64 box: rounded outward, then padded
+void cull_box(const Aabb &b, float lo[3], float hi[3]);
 
 // PerspectiveCamera::new (src/camera.rs:25-59)
 void camera_perspective(RtCameraD *out, const double eye[3], const double center[3], const double up[3], double fov,

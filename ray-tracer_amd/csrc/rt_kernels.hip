@@ -1,14 +1,32 @@
 // rt_kernels.hip -- HIP kernels for gfx950 (MI355X).  The only compute path of
 // librt_mi355x.so: there is no CPU fallback.
 //
-// render_kernel: one 64-lane wavefront owns one 8x8 pixel tile; lane = pixel.
-// Every lane runs ONE flattened loop over (sample, path segment): when a path
-// ends the lane folds its radiance into the pixel sum -- in sample order, so the
-// sum rounds exactly like `pixel += color(...)` in examples/book-one.rs:69-75 --
-// and regenerates the next sample's camera ray in place.  Lanes never wait for
-// each other at sample boundaries; the wave retires when its 64 pixels are done.
-// The BVH traversal stack lives in LDS, laid out [depth][thread] so that a
-// push/pop by all 64 lanes is one conflict-free ds_write/ds_read_b32.
+// render_kernel -- persistent wavefronts, wave-vote scheduling.
+//   Every lane owns one camera path at a time and is in one of three states:
+//   NODE (at an inner BVH node), LEAF (at a primitive), DONE (traversal finished,
+//   waiting to be shaded).  Each trip round the loop the wave ballots the states
+//   and runs exactly ONE of three blocks for the lanes in that state:
+//     node block  -- binary32 slab tests of both children (culling only), ordered
+//                    descent, LDS stack push/pop with tnear culling;
+//     leaf block  -- the binary64 primitive test (the reference's arithmetic);
+//     shade block -- binary64 hit record + Material::scatter, then the next
+//                    segment; a finished path stores its radiance and the lane
+//                    immediately takes the next sample of the wave's job queue
+//                    (jobs = 8x8-pixel tile x RT_JOB_SPP samples, drawn from one
+//                    device-wide atomic counter).
+//   The expensive blocks only run when enough lanes have queued up for them (or
+//   nothing else can run), so each block executes at high SIMD occupancy instead
+//   of every lane dragging the other 63 through its own branch.  Lanes never idle
+//   at sample, pixel or tile boundaries; a wave retires only when the job queue
+//   is empty.  Scheduling never changes a result: each path consumes its own
+//   counter-based random stream and every sample is an independent value.
+//   The traversal stack lives in LDS, [depth][thread], conflict-free ds_read/write_b32.
+//
+// reduce_kernel -- pixel = (((s_0 + s_1) + s_2) + ...) / spp in sample order, the
+//   rounding of `pixel += color(...)` in examples/book-one.rs:69-76.  Per-sample
+//   radiance takes 24 B/sample of HBM (11.5 GB for 1200x800x500; the MI355X has
+//   288 GB) and ~2 x 24 B/sample of traffic, noise next to the traversal.
+//
 // No MFMA anywhere: the workload has no dense contraction.
 
 #include <hip/hip_runtime.h>
@@ -16,87 +34,226 @@
 #include "rt_lane.h"
 #include "rt_types.h"
 
-#define RT_BLOCK 256 /* 4 waves = 4 tiles per workgroup */
+#define RT_BLOCK 256 /* 4 waves per workgroup */
+
+// vote thresholds (lanes).  A block runs when at least this many lanes wait for
+// it, or when no cheaper block has work.
+#ifndef RT_VOTE_SHADE
+#define RT_VOTE_SHADE 24
+#endif
+#ifndef RT_VOTE_LEAF
+#define RT_VOTE_LEAF 16
+#endif
+#ifndef RT_NODE_KEEP
+#define RT_NODE_KEEP 20
+#endif
+#ifndef RT_WAVES_PER_EU
+#define RT_WAVES_PER_EU 4
+#endif
 
 namespace {
 
 struct LdsStack {
-    int32_t *base; // &stack[threadIdx.x]
-    int sp;
-    __device__ __forceinline__ void reset() { sp = 0; }
-    __device__ __forceinline__ void push(int32_t v) {
+    uint32_t *base; // &stack[threadIdx.x]
+    __device__ __forceinline__ void push(int32_t &sp, uint32_t v) {
         base[sp * RT_BLOCK] = v;
         ++sp;
     }
-    __device__ __forceinline__ int32_t pop() {
+    __device__ __forceinline__ uint32_t pop(int32_t &sp) {
         --sp;
         return base[sp * RT_BLOCK];
     }
-    __device__ __forceinline__ bool empty() const { return sp == 0; }
 };
 
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) { // set bits below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 template <bool GENERAL, bool MEDIUM, bool TEXTURED, bool LENS, bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void render_kernel(const RtLaunch L) {
-    __shared__ int32_t stack_mem[RT_STACK_DEPTH * RT_BLOCK];
-
-    const int lane = threadIdx.x & 63;
-    const int k = blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6); // ordinal of the owned tile
-    if (k >= L.n_owned_tiles) return;                                // wave-uniform
-    const int tile = L.shard_index + k * L.shard_count;
-    const int tx = tile % L.tiles_x, ty = tile / L.tiles_x;
-    const uint32_t x = (uint32_t)(tx * RT_TILE_EDGE + (lane & 7));
-    const uint32_t y = (uint32_t)(ty * RT_TILE_EDGE + (lane >> 3));
-    const bool inside = x < (uint32_t)L.width && y < (uint32_t)L.height;
-
+__global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void render_kernel(const RtLaunch L) {
+    __shared__ uint32_t stack_mem[RT_STACK_DEPTH * RT_BLOCK];
     LdsStack st;
     st.base = stack_mem + threadIdx.x;
-    st.sp = 0;
 
-    rtl::V3 acc = rtl::mk(0.0, 0.0, 0.0);
     rtl::PathState ps;
-    unsigned long long nodes = 0, prims = 0, segs = 0, draws = 0, witers = 0;
+    rtl::Trav tv;
+    tv.cur = RT_CUR_DONE;
+    tv.sp = 0;
+    tv.best_prim = 0xFFFFFFFFu;
+    tv.best_t = 0.0;
+    bool has_path = false;
+    uint32_t slot = 0; // index of this lane's sample in L.samples
 
-    int s = inside ? 0 : L.spp;
-    bool fresh = true;
-    while (s < L.spp) {
-        if (fresh) {
-            rtl::start_sample<LENS>(L, x, y, (uint32_t)s, &ps);
-            fresh = false;
-        }
-        if (COUNT) {
-            ++segs;
-            // count this wave-iteration once: by the lowest active lane
-            if (__ffsll((unsigned long long)__ballot(1)) - 1 == lane) ++witers;
-        }
-        const bool done = rtl::advance_segment<GENERAL, MEDIUM, TEXTURED>(L, &ps, st, &nodes, &prims);
-        if (done) {
-            acc = acc + ps.Lsum; // pixel += color(...)
-            if (COUNT) draws += ps.g.draws;
-            ++s;
-            fresh = true;
+    // wave-uniform job state
+    uint32_t job_next = 0, job_left = 0, job_slot0 = 0, job_x0 = 0, job_y0 = 0, job_s_first = 0;
+    bool queue_empty = false;
+
+    unsigned long long c_nodes = 0, c_prims = 0, c_segs = 0, c_draws = 0, c_samples = 0;
+    unsigned long long c_nw = 0, c_nl = 0, c_lw = 0, c_ll = 0, c_sw = 0, c_sl = 0;
+    const bool counting_lane = COUNT && (threadIdx.x & 63) == 0;
+
+    for (;;) {
+        const bool is_done = tv.cur == RT_CUR_DONE;
+        const bool is_leaf = (tv.cur & (RT_REF_LEAF | RT_CUR_DONE | RT_CUR_DEAD)) == RT_REF_LEAF;
+        const bool is_node = tv.cur < RT_REF_LEAF;
+        const unsigned long long mS = __ballot(is_done), mL = __ballot(is_leaf), mN = __ballot(is_node);
+        if ((mS | mL | mN) == 0ull) break; // every lane is dead
+        const int nS = __popcll(mS), nL = __popcll(mL), nN = __popcll(mN);
+
+        if (nS >= RT_VOTE_SHADE || (nN == 0 && nL == 0)) {
+            // ---------------- shade block ----------------
+            if (COUNT && counting_lane) {
+                ++c_sw;
+                c_sl += (unsigned long long)nS;
+            }
+            bool need = false;
+            if (is_done) {
+                if (has_path) {
+                    if (COUNT) ++c_segs;
+                    if (rtl::finish_segment<GENERAL, MEDIUM, TEXTURED>(L, &ps, tv)) {
+                        double *o = L.samples + (size_t)slot * 3;
+                        o[0] = ps.Lsum.x;
+                        o[1] = ps.Lsum.y;
+                        o[2] = ps.Lsum.z;
+                        has_path = false;
+                        if (COUNT) {
+                            c_draws += ps.g.draws;
+                            ++c_samples;
+                        }
+                    }
+                }
+                need = !has_path;
+            }
+            // refill: lanes without a path take the next samples of the job queue.  Executed by the
+            // whole wave (wave-uniform control flow) so the job state stays identical in every lane.
+            for (;;) {
+                const unsigned long long m = __ballot(need);
+                if (m == 0ull) break;
+                if (job_left == 0u) {
+                    if (queue_empty) break;
+                    uint32_t j = 0;
+                    if (need && lane_rank(m) == 0u) j = atomicAdd(L.job_counter, 1u);
+                    j = (uint32_t)__builtin_amdgcn_readlane((int)j, __ffsll((long long)m) - 1); // fetched by the first needing lane
+                    if (j >= (uint32_t)L.n_jobs) {
+                        queue_empty = true;
+                        break;
+                    }
+                    const uint32_t k = j / (uint32_t)L.jobs_per_tile, sub = j - k * (uint32_t)L.jobs_per_tile;
+                    const uint32_t tile = (uint32_t)L.shard_index + k * (uint32_t)L.shard_count;
+                    const uint32_t ty = tile / (uint32_t)L.tiles_x, tx = tile - ty * (uint32_t)L.tiles_x;
+                    job_x0 = tx * RT_TILE_EDGE;
+                    job_y0 = ty * RT_TILE_EDGE;
+                    job_s_first = sub * RT_JOB_SPP;
+                    const uint32_t nspp = min((uint32_t)RT_JOB_SPP, (uint32_t)L.s_count - job_s_first);
+                    job_left = nspp * RT_TILE_PIXELS;
+                    job_next = 0u;
+                    job_slot0 = (k * (uint32_t)L.s_count + job_s_first) * RT_TILE_PIXELS;
+                }
+                const uint32_t take = min((uint32_t)__popcll(m), job_left);
+                const uint32_t rank = lane_rank(m);
+                if (need && rank < take) {
+                    const uint32_t n = job_next + rank;
+                    const uint32_t pix = n & 63u;
+                    const uint32_t x = job_x0 + (pix & 7u), y = job_y0 + (pix >> 3);
+                    if (x < (uint32_t)L.width && y < (uint32_t)L.height) {
+                        slot = job_slot0 + n;
+                        rtl::start_sample<LENS>(L, x, y, (uint32_t)L.s0 + job_s_first + (n >> 6), &ps);
+                        has_path = true;
+                        need = false;
+                    }
+                    // a pixel outside the image consumes its slot and the lane asks again
+                }
+                job_next += take;
+                job_left -= take;
+            }
+            if (is_done) {
+                if (has_path)
+                    rtl::begin_segment<GENERAL, MEDIUM, TEXTURED>(L, &ps, tv, st, &c_prims);
+                else
+                    tv.cur = RT_CUR_DEAD;
+            }
+        } else if (nL >= RT_VOTE_LEAF || nN == 0) {
+            // ---------------- leaf block ----------------
+            if (COUNT && counting_lane) {
+                ++c_lw;
+                c_ll += (unsigned long long)nL;
+            }
+            if (is_leaf) rtl::leaf_step<GENERAL, MEDIUM, TEXTURED>(L, &ps, tv, st, &c_prims);
+        } else {
+            // ---------------- node block ----------------
+            for (;;) {
+                const bool at_node = tv.cur < RT_REF_LEAF;
+                const int n = __popcll(__ballot(at_node));
+                if (n == 0) break;
+                if (COUNT && counting_lane) {
+                    ++c_nw;
+                    c_nl += (unsigned long long)n;
+                }
+                if (at_node) {
+                    if (COUNT) ++c_nodes;
+                    rtl::trav_node_step(L, tv, st);
+                }
+                if (n < RT_NODE_KEEP) break;
+            }
         }
     }
 
-    double *o = L.out + ((size_t)k * RT_TILE_PIXELS + (size_t)lane) * 3;
-    if (inside) {
-        const double n = (double)L.spp; // pixel /= subPixelSampleCount
-        o[0] = acc.x / n;
-        o[1] = acc.y / n;
-        o[2] = acc.z / n;
-    } else {
-        o[0] = 0.0;
-        o[1] = 0.0;
-        o[2] = 0.0;
-    }
     if (COUNT && L.counters) {
-        if (inside) atomicAdd(&L.counters->samples, (unsigned long long)L.spp);
-        atomicAdd(&L.counters->segments, segs);
-        atomicAdd(&L.counters->nodes_visited, nodes);
-        atomicAdd(&L.counters->prims_tested, prims);
-        atomicAdd(&L.counters->rng_draws, draws);
-        atomicAdd(&L.counters->wave_iterations, witers);
-        atomicAdd(&L.counters->lane_iterations, segs);
+        atomicAdd(&L.counters->samples, c_samples);
+        atomicAdd(&L.counters->segments, c_segs);
+        atomicAdd(&L.counters->nodes_visited, c_nodes);
+        atomicAdd(&L.counters->prims_tested, c_prims);
+        atomicAdd(&L.counters->rng_draws, c_draws);
+        if (counting_lane) {
+            atomicAdd(&L.counters->node_wave, c_nw);
+            atomicAdd(&L.counters->node_lane, c_nl);
+            atomicAdd(&L.counters->leaf_wave, c_lw);
+            atomicAdd(&L.counters->leaf_lane, c_ll);
+            atomicAdd(&L.counters->shade_wave, c_sw);
+            atomicAdd(&L.counters->shade_lane, c_sl);
+        }
     }
+}
+
+// Sum this pass's samples in sample order on top of the running sums; the last
+// pass divides by spp (`pixel /= subPixelSampleCount`, examples/book-one.rs:76).
+// One thread per owned pixel; consecutive threads read consecutive 24-byte records.
+__global__ void reduce_kernel(const double *samples, double *tiles, int n_owned_tiles, int s_count, int first_pass,
+                              int last_pass, int spp, int width, int height, int tiles_x, int shard_index, int shard_count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_owned_tiles * RT_TILE_PIXELS) return;
+    const size_t k = i / RT_TILE_PIXELS;
+    const int pix = (int)(i % RT_TILE_PIXELS);
+    const int tile = shard_index + (int)k * shard_count;
+    const int x = (tile % tiles_x) * RT_TILE_EDGE + (pix & 7), y = (tile / tiles_x) * RT_TILE_EDGE + (pix >> 3);
+    double *out = tiles + i * 3;
+    if (x >= width || y >= height) {
+        out[0] = out[1] = out[2] = 0.0;
+        return;
+    }
+    double r = 0.0, g = 0.0, b = 0.0;
+    if (!first_pass) {
+        r = out[0];
+        g = out[1];
+        b = out[2];
+    }
+    const double *p = samples + ((size_t)k * (size_t)s_count * RT_TILE_PIXELS + (size_t)pix) * 3;
+    for (int s = 0; s < s_count; ++s) {
+        r += p[0];
+        g += p[1];
+        b += p[2];
+        p += RT_TILE_PIXELS * 3;
+    }
+    if (last_pass) {
+        const double n = (double)spp;
+        r /= n;
+        g /= n;
+        b /= n;
+    }
+    out[0] = r;
+    out[1] = g;
+    out[2] = b;
 }
 
 // gathered shards -> row-major image.  One thread per (pixel, channel).
@@ -122,9 +279,7 @@ __global__ void probe_math_kernel(const double *a, const double *b, int n, doubl
 }
 
 template <bool GENERAL, bool MEDIUM, bool TEXTURED>
-hipError_t launch3(const RtLaunch &L, bool lens, bool count, hipStream_t stream) {
-    const int blocks = (L.n_owned_tiles + (RT_BLOCK / 64) - 1) / (RT_BLOCK / 64);
-    if (blocks <= 0) return hipSuccess;
+hipError_t launch3(const RtLaunch &L, bool lens, bool count, int blocks, hipStream_t stream) {
     dim3 g((unsigned)blocks), b(RT_BLOCK);
     if (lens) {
         if (count)
@@ -142,14 +297,24 @@ hipError_t launch3(const RtLaunch &L, bool lens, bool count, hipStream_t stream)
 
 } // namespace
 
-// feature bits: 1 = general prims, 2 = media, 4 = textured
-extern "C" int rt_launch_render(const RtLaunch *L, unsigned features, int lens, int count, void *stream) {
+// feature bits: 1 = general prims, 2 = media, 4 = textured.  `blocks` persistent workgroups.
+extern "C" int rt_launch_render(const RtLaunch *L, unsigned features, int lens, int count, int blocks, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
     if (features == 0u)
-        e = launch3<false, false, false>(*L, lens != 0, count != 0, s);
+        e = launch3<false, false, false>(*L, lens != 0, count != 0, blocks, s);
     else
-        e = launch3<true, true, true>(*L, lens != 0, count != 0, s);
+        e = launch3<true, true, true>(*L, lens != 0, count != 0, blocks, s);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int rt_launch_reduce(const double *samples, double *tiles, int n_owned_tiles, int s_count, int first_pass, int last_pass,
+                                int spp, int width, int height, int shard_index, int shard_count, void *stream) {
+    const size_t n = (size_t)n_owned_tiles * RT_TILE_PIXELS;
+    const int tiles_x = (width + RT_TILE_EDGE - 1) / RT_TILE_EDGE;
+    hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, samples, tiles,
+                       n_owned_tiles, s_count, first_pass, last_pass, spp, width, height, tiles_x, shard_index, shard_count);
+    hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
 
@@ -168,4 +333,34 @@ extern "C" int rt_launch_probe_math(const double *a, const double *b, int n, dou
                        out_div);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
+}
+
+// occupancy-derived size of the persistent grid
+extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int *blocks_per_cu, int *n_cu) {
+    int per_cu = 0;
+    hipError_t e;
+#define RT_OCC(G, M, T, LN, C) \
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)render_kernel<G, M, T, LN, C>, RT_BLOCK, 0)
+    if (features == 0u) {
+        if (lens) {
+            if (count) RT_OCC(false, false, false, true, true); else RT_OCC(false, false, false, true, false);
+        } else {
+            if (count) RT_OCC(false, false, false, false, true); else RT_OCC(false, false, false, false, false);
+        }
+    } else {
+        if (lens) {
+            if (count) RT_OCC(true, true, true, true, true); else RT_OCC(true, true, true, true, false);
+        } else {
+            if (count) RT_OCC(true, true, true, false, true); else RT_OCC(true, true, true, false, false);
+        }
+    }
+#undef RT_OCC
+    if (e != hipSuccess) return (int)e;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return (int)e;
+    if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return (int)e;
+    *blocks_per_cu = per_cu;
+    *n_cu = prop.multiProcessorCount;
+    return 0;
 }

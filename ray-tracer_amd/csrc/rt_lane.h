@@ -235,30 +235,32 @@ struct SegCtx { // what a primitive test may need besides the ray
 // RECORD = false: only r->t is meaningful (traversal); true: full record (shading).
 template <bool GENERAL, bool MEDIUM, bool UV, bool RECORD>
 RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx &sc, Rec *r) {
-    const RtPrim &P = L.prims[pi];
-    const uint32_t kind = (GENERAL || MEDIUM) ? P.kind : (uint32_t)RT_PRIM_SPHERE_T;
+    const RtPrimGeo &G = L.prim_geo[pi];
+    uint32_t kind = (uint32_t)RT_PRIM_SPHERE_T;
+    if (GENERAL || MEDIUM) kind = L.prim_meta[pi].kind;
     ++sc.prims_tested;
     if (kind == RT_PRIM_SPHERE_T) {
         // Sprite::hit with a translation matrix: M^-1 (o,1) = o - c, M^-1 (d,0) = d,
         // M (p,1) = p + c, M (n,0) = n  (src/sprite.rs:101-126, src/vec4.rs:78-91)
-        V3 c = mk(P.g[0], P.g[1], P.g[2]);
+        V3 c = mk(G.g[0], G.g[1], G.g[2]);
         V3 oc = o - c;
         double t;
-        if (!sphere_t(oc, d, a, P.g[3], &t)) return false;
+        if (!sphere_t(oc, d, a, G.g[3], &t)) return false;
         r->t = t;
         if (RECORD) {
-            sphere_finish<UV>(oc, d, P.g[3], t, r);
+            sphere_finish<UV>(oc, d, G.g[3], t, r);
             r->p = r->p + c;
         }
         return true;
     }
-    if (MEDIUM && kind == RT_PRIM_MEDIUM_T) {
-        V3 c = mk(P.g[0], P.g[1], P.g[2]);
-        if (!medium_hit<UV>(o - c, d, P.g[3], P.g2[0], sc.rng_base, sc.segment, P.aux, &sc.draws, r)) return false;
-        if (RECORD) r->p = r->p + c;
-        return true;
-    }
     if (GENERAL || MEDIUM) {
+        const RtPrimMeta &P = L.prim_meta[pi];
+        if (MEDIUM && kind == RT_PRIM_MEDIUM_T) {
+            V3 c = mk(G.g[0], G.g[1], G.g[2]);
+            if (!medium_hit<UV>(o - c, d, G.g[3], L.prim_extra[pi].e[0], sc.rng_base, sc.segment, P.aux, &sc.draws, r)) return false;
+            if (RECORD) r->p = r->p + c;
+            return true;
+        }
         const RtXform &X = L.xforms[P.xform];
         V3 lo = xf_point(X.inv, o);
         V3 ld = xf_vector(X.inv, d); // not renormalised (quirk Q5)
@@ -266,26 +268,26 @@ RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx
         if (kind == RT_PRIM_SPHERE_M) {
             double la = dot(ld, ld);
             double t;
-            if (sphere_t(lo, ld, la, P.g[0], &t)) {
+            if (sphere_t(lo, ld, la, G.g[0], &t)) {
                 ok = true;
                 r->t = t;
-                if (RECORD) sphere_finish<UV>(lo, ld, P.g[0], t, r);
+                if (RECORD) sphere_finish<UV>(lo, ld, G.g[0], t, r);
             }
         } else if (kind == RT_PRIM_RECT_M) {
-            ok = rect_hit(lo, ld, P.g[0], P.g[1], r);
+            ok = rect_hit(lo, ld, G.g[0], G.g[1], r);
         } else if (kind == RT_PRIM_GROUP_M) {
             // BoundingVolumeHierarchyNode over the faces (src/optimize.rs:469-498):
             // nearest face, strict <, first face wins ties; the boxes only filter
-            const uint32_t first = P.aux, count = (uint32_t)P.g[0];
+            const uint32_t first = P.aux, count = (uint32_t)G.g[0];
             double best = RTL_INF;
             for (uint32_t k = 0; k < count; ++k) {
-                const RtPrim &C = L.prims[first + k];
-                const RtXform &CX = L.xforms[C.xform];
+                const RtPrimGeo &CG = L.prim_geo[first + k];
+                const RtXform &CX = L.xforms[L.prim_meta[first + k].xform];
                 V3 co = xf_point(CX.inv, lo);
                 V3 cd = xf_vector(CX.inv, ld);
                 Rec cr;
                 ++sc.prims_tested;
-                if (rect_hit(co, cd, C.g[0], C.g[1], &cr) && cr.t < best) {
+                if (rect_hit(co, cd, CG.g[0], CG.g[1], &cr) && cr.t < best) {
                     best = cr.t;
                     if (RECORD) to_world(CX, &cr); // TransformedGeometry::hit, src/geometry.rs:228-236
                     *r = cr;
@@ -293,7 +295,7 @@ RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx
                 }
             }
         } else if (MEDIUM && kind == RT_PRIM_MEDIUM_M) {
-            ok = medium_hit<UV>(lo, ld, P.g[0], P.g[1], sc.rng_base, sc.segment, P.aux, &sc.draws, r);
+            ok = medium_hit<UV>(lo, ld, G.g[0], G.g[1], sc.rng_base, sc.segment, P.aux, &sc.draws, r);
         }
         if (!ok) return false;
         if (RECORD) to_world(X, r);
@@ -302,96 +304,149 @@ RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx
     return false;
 }
 
-// ---- AxisAlignedBoundingBox::hit (src/optimize.rs:61-82) restricted to [0, tmax]:
-// the reference never prunes by the best hit so far; stopping at tmax cannot change
-// the nearest hit, it only skips boxes that start behind it.  idir = 1/d. ----
-RT_HD bool slab(const double *lo, const double *hi, V3 o, V3 idir, double tmax_in, double *tnear) {
-    double tmin = 0.0, tmax = tmax_in;
-    {
-        double t0 = (lo[0] - o.x) * idir.x, t1 = (hi[0] - o.x) * idir.x;
-        if (idir.x < 0.0) {
-            double s = t0;
-            t0 = t1;
-            t1 = s;
-        }
-        tmin = t0 > tmin ? t0 : tmin;
-        tmax = t1 < tmax ? t1 : tmax;
-        if (tmax < tmin) return false;
-    }
-    {
-        double t0 = (lo[1] - o.y) * idir.y, t1 = (hi[1] - o.y) * idir.y;
-        if (idir.y < 0.0) {
-            double s = t0;
-            t0 = t1;
-            t1 = s;
-        }
-        tmin = t0 > tmin ? t0 : tmin;
-        tmax = t1 < tmax ? t1 : tmax;
-        if (tmax < tmin) return false;
-    }
-    {
-        double t0 = (lo[2] - o.z) * idir.z, t1 = (hi[2] - o.z) * idir.z;
-        if (idir.z < 0.0) {
-            double s = t0;
-            t0 = t1;
-            t1 = s;
-        }
-        tmin = t0 > tmin ? t0 : tmin;
-        tmax = t1 < tmax ? t1 : tmax;
-        if (tmax < tmin) return false;
-    }
-    *tnear = tmin;
-    return true;
+// ---------------------------------------------------------------- traversal
+// The reference's BVH walk (src/optimize.rs:469-498) visits every box the ray
+// touches in [0, inf), never prunes, never orders; its result is the nearest
+// primitive hit, whatever the tree.  Here the boxes are binary32 CULLING volumes
+// (rounded outward + padded, rt_host.cpp cull_box) tested against a binary32 image
+// of the ray with a per-ray pad, in [0, best_t]: they decide only which binary64
+// primitive tests are skipped, and a skipped test is one that could not win.
+// Every hit/miss/nearest decision is made by prim_hit in binary64.
+struct Trav {
+    uint32_t cur;        // 16-bit node/leaf reference, RT_CUR_DONE, RT_CUR_DEAD
+    int32_t sp;          // stack pointer (entries live in the Stack policy object)
+    double best_t;
+    uint32_t best_prim;
+    float best32;        // best_t rounded up to binary32
+    float idx, idy, idz; // 1 / d
+    float nx, ny, nz;    // -(o/d + pad): entry planes,  t = plane * id + n
+    float fx, fy, fz;    // -(o/d - pad): exit planes
+};
+
+RT_HD float up32(double t) { // >= t in binary32
+    float f = (float)t;
+    return f * 1.0000005f;
+}
+RT_HD float bits_f32(uint32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f;
+    memcpy(&f, &u, sizeof f);
+    return f;
+#endif
+}
+RT_HD uint32_t f32_bits(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_uint(f);
+#else
+    uint32_t u;
+    memcpy(&u, &f, sizeof u);
+    return u;
+#endif
 }
 
-// Nearest hit over the flat BVH.  Stack is any type with push(int) / pop() / empty().
-// Result is independent of visiting order: nearest t, ties to the lower prim id.
-template <bool GENERAL, bool MEDIUM, bool UV, class Stack>
-RT_HD bool trace(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Stack &st, unsigned long long *nodes_visited, uint32_t *hit_prim,
-                 double *hit_t) {
-    const double a = dot(d, d);
-    const V3 idir = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-    double best_t = RTL_INF;
-    uint32_t best_prim = 0xFFFFFFFFu;
-    int32_t cur = L.root;
-    st.reset();
+// next node from the stack, skipping entries that start behind the best hit
+template <class Stack>
+RT_HD void trav_pop(Trav &tv, Stack &st) {
     for (;;) {
-        if (cur >= 0) {
-            const RtNode &N = L.nodes[cur];
-            ++*nodes_visited;
-            double n0, n1;
-            const bool h0 = slab(N.lo0, N.hi0, o, idir, best_t, &n0);
-            const bool h1 = slab(N.lo1, N.hi1, o, idir, best_t, &n1);
-            if (h0 && h1) {
-                const bool first0 = !(n1 < n0);
-                st.push(first0 ? N.child1 : N.child0);
-                cur = first0 ? N.child0 : N.child1;
-                continue;
-            }
-            if (h0) {
-                cur = N.child0;
-                continue;
-            }
-            if (h1) {
-                cur = N.child1;
-                continue;
-            }
-        } else {
-            const uint32_t pi = (uint32_t)~cur;
-            Rec r;
-            if (prim_hit<GENERAL, MEDIUM, UV, false>(L, pi, o, d, a, sc, &r)) {
-                if (r.t < best_t || (r.t == best_t && pi < best_prim)) {
-                    best_t = r.t;
-                    best_prim = pi;
-                }
+        if (tv.sp == 0) {
+            tv.cur = RT_CUR_DONE;
+            return;
+        }
+        const uint32_t e = st.pop(tv.sp);
+        if (bits_f32(e & 0xFFFF0000u) > tv.best32) continue; // stored tnear is rounded DOWN: conservative
+        tv.cur = e & 0xFFFFu;
+        return;
+    }
+}
+
+// start a segment: binary32 ray constants, hoisted prims, root
+template <bool GENERAL, bool MEDIUM, bool UV, class Stack>
+RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack &st) {
+    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+    tv.idx = 1.0f / (float)d.x;
+    tv.idy = 1.0f / (float)d.y;
+    tv.idz = 1.0f / (float)d.z;
+    // the binary32 ray is displaced from the binary64 one by <= 2^-24 (|o| + t|d|) per axis;
+    // the box pad covers the |o + t d| share, this pad the |o| share (>2x margin each)
+    const float e = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) * 0x1p-21f + 1e-30f;
+    const float qx = ox * tv.idx, qy = oy * tv.idy, qz = oz * tv.idz;
+    const float ex = e * fabsf(tv.idx), ey = e * fabsf(tv.idy), ez = e * fabsf(tv.idz);
+    tv.nx = -(qx + ex);
+    tv.ny = -(qy + ey);
+    tv.nz = -(qz + ez);
+    tv.fx = -(qx - ex);
+    tv.fy = -(qy - ey);
+    tv.fz = -(qz - ez);
+    tv.best_t = RTL_INF;
+    tv.best_prim = 0xFFFFFFFFu;
+    const double a = dot(d, d);
+    for (int32_t pi = 0; pi < L.n_hoisted; ++pi) {
+        Rec r;
+        if (prim_hit<GENERAL, MEDIUM, UV, false>(L, (uint32_t)pi, o, d, a, sc, &r)) {
+            if (r.t < tv.best_t) { // ascending prim id: ties keep the lower id
+                tv.best_t = r.t;
+                tv.best_prim = (uint32_t)pi;
             }
         }
-        if (st.empty()) break;
-        cur = st.pop();
     }
-    *hit_prim = best_prim;
-    *hit_t = best_t;
-    return best_prim != 0xFFFFFFFFu;
+    tv.best32 = up32(tv.best_t);
+    tv.sp = 0;
+    tv.cur = L.root;
+}
+
+// one inner-node step (tv.cur is an inner node reference)
+template <class Stack>
+RT_HD void trav_node_step(const RtLaunch &L, Trav &tv, Stack &st) {
+    const RtNode &N = L.nodes[tv.cur];
+    float tmin[2], tmax[2];
+    bool hit[2];
+    for (int c = 0; c < 2; ++c) {
+        // fminf / fmaxf ignore a NaN operand (0 * inf planes), like the reference's selects
+        const float ax = fmaf(N.lo_x[c], tv.idx, tv.nx), bx = fmaf(N.hi_x[c], tv.idx, tv.nx);
+        const float ay = fmaf(N.lo_y[c], tv.idy, tv.ny), by = fmaf(N.hi_y[c], tv.idy, tv.ny);
+        const float az = fmaf(N.lo_z[c], tv.idz, tv.nz), bz = fmaf(N.hi_z[c], tv.idz, tv.nz);
+        const float cx = fmaf(N.lo_x[c], tv.idx, tv.fx), dx = fmaf(N.hi_x[c], tv.idx, tv.fx);
+        const float cy = fmaf(N.lo_y[c], tv.idy, tv.fy), dy = fmaf(N.hi_y[c], tv.idy, tv.fy);
+        const float cz = fmaf(N.lo_z[c], tv.idz, tv.fz), dz = fmaf(N.hi_z[c], tv.idz, tv.fz);
+        tmin[c] = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+        tmax[c] = fminf(fminf(fmaxf(cx, dx), fmaxf(cy, dy)), fminf(fmaxf(cz, dz), tv.best32));
+        hit[c] = tmin[c] <= tmax[c] * 1.000001f; // slack for the rounding of the slab arithmetic itself
+    }
+    if (hit[0] && hit[1]) {
+        const int nearc = tmin[1] < tmin[0] ? 1 : 0;
+        const int farc = 1 - nearc;
+        st.push(tv.sp, (f32_bits(tmin[farc]) & 0xFFFF0000u) | N.child[farc]);
+        tv.cur = N.child[nearc];
+        return;
+    }
+    if (hit[0]) {
+        tv.cur = N.child[0];
+        return;
+    }
+    if (hit[1]) {
+        tv.cur = N.child[1];
+        return;
+    }
+    trav_pop(tv, st);
+}
+
+// one leaf step (tv.cur is a leaf reference): binary64 primitive test, then pop
+template <bool GENERAL, bool MEDIUM, bool UV, class Stack>
+RT_HD void trav_leaf_step(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack &st) {
+    const uint32_t pi = tv.cur & RT_REF_MAX;
+    const double a = dot(d, d);
+    Rec r;
+    if (prim_hit<GENERAL, MEDIUM, UV, false>(L, pi, o, d, a, sc, &r)) {
+        // nearest t; exact ties go to the lower prim id, whatever the visiting order
+        if (r.t < tv.best_t || (r.t == tv.best_t && pi < tv.best_prim)) {
+            tv.best_t = r.t;
+            tv.best_prim = pi;
+            tv.best32 = up32(r.t);
+        }
+    }
+    trav_pop(tv, st);
 }
 
 // ---- Texture::value (src/material.rs:211-215,235-245; examples/main.rs:267-280) ----
@@ -488,14 +543,14 @@ RT_HD bool shade(const RtLaunch &L, const RtMaterial &M, const Rec &rec, V3 d_in
     return false;
 }
 
-// One whole sample (jitter -> camera ray -> iterative color()); used by the kernel's
-// flattened loop piecewise and by the host diff harness as a whole.
+// ---------------------------------------------------------------- path state
 struct PathState {
     V3 o, d, T, Lsum;
     Rng g;
     int32_t k; // segments traced so far
 };
 
+// examples/book-one.rs:69-73: stream, jitter, camera ray
 template <bool LENS>
 RT_HD void start_sample(const RtLaunch &L, uint32_t x, uint32_t y, uint32_t s, PathState *ps) {
     const uint64_t pixel = (uint64_t)y * (uint64_t)L.width + (uint64_t)x;
@@ -503,7 +558,6 @@ RT_HD void start_sample(const RtLaunch &L, uint32_t x, uint32_t y, uint32_t s, P
     ps->g.base = L.seed_mix + (stream << RT_RNG_STREAM_SHIFT) * RT_RNG_GAMMA;
     ps->g.s = ps->g.base;
     ps->g.draws = 0;
-    // examples/book-one.rs:71-73
     double u = ((double)x + rng_range01(ps->g)) / (double)L.width;
     double v = ((double)y + rng_range01(ps->g)) / (double)L.height;
     camera_ray<LENS>(L.cam, u, v, ps->g, &ps->o, &ps->d);
@@ -512,37 +566,53 @@ RT_HD void start_sample(const RtLaunch &L, uint32_t x, uint32_t y, uint32_t s, P
     ps->k = 0;
 }
 
-// Trace + shade one segment of render::color (src/render.rs:5-29, iterative form
-// L = sum_k (prod_{j<k} att_j) * e_k).  Returns true when the sample is finished.
 template <bool GENERAL, bool MEDIUM, bool TEXTURED, class Stack>
-RT_HD bool advance_segment(const RtLaunch &L, PathState *ps, Stack &st, unsigned long long *nodes_visited,
-                           unsigned long long *prims_tested) {
-    constexpr bool UV = TEXTURED;
+RT_HD void begin_segment(const RtLaunch &L, PathState *ps, Trav &tv, Stack &st, unsigned long long *prims_tested) {
     SegCtx sc;
     sc.rng_base = ps->g.base;
     sc.segment = (uint32_t)ps->k;
     sc.draws = 0;
     sc.prims_tested = 0;
-    uint32_t prim;
-    double t;
-    const bool hit = trace<GENERAL, MEDIUM, UV>(L, ps->o, ps->d, sc, st, nodes_visited, &prim, &t);
+    trav_begin<GENERAL, MEDIUM, TEXTURED>(L, ps->o, ps->d, sc, tv, st);
     ps->g.draws += sc.draws;
     *prims_tested += sc.prims_tested;
-    if (!hit) return true; // background is black (src/render.rs:21-28)
-    const uint32_t mat = L.prims[prim].material;
+}
+
+template <bool GENERAL, bool MEDIUM, bool TEXTURED, class Stack>
+RT_HD void leaf_step(const RtLaunch &L, PathState *ps, Trav &tv, Stack &st, unsigned long long *prims_tested) {
+    SegCtx sc;
+    sc.rng_base = ps->g.base;
+    sc.segment = (uint32_t)ps->k;
+    sc.draws = 0;
+    sc.prims_tested = 0;
+    trav_leaf_step<GENERAL, MEDIUM, TEXTURED>(L, ps->o, ps->d, sc, tv, st);
+    ps->g.draws += sc.draws;
+    *prims_tested += sc.prims_tested;
+}
+
+// The traversal of this segment is finished (tv.cur == RT_CUR_DONE): shade it.
+// render::color, src/render.rs:5-29, in its iterative form
+// L = sum_k (prod_{j<k} att_j) * e_k.  Returns true when the sample is finished.
+template <bool GENERAL, bool MEDIUM, bool TEXTURED>
+RT_HD bool finish_segment(const RtLaunch &L, PathState *ps, const Trav &tv) {
+    constexpr bool UV = TEXTURED;
+    if (tv.best_prim == 0xFFFFFFFFu) return true; // background is black (src/render.rs:21-28)
+    const uint32_t prim = tv.best_prim;
+    const uint32_t mat = L.prim_meta[prim].material;
     if (mat == RT_NO_MATERIAL) return true; // src/render.rs:18-20
     Rec rec;
-    {
-        const double a = dot(ps->d, ps->d);
-        if (GENERAL || MEDIUM) {
-            SegCtx sc2 = sc;
-            prim_hit<GENERAL, MEDIUM, UV, true>(L, prim, ps->o, ps->d, a, sc2, &rec);
-        } else {
-            const RtPrim &P = L.prims[prim];
-            V3 c = mk(P.g[0], P.g[1], P.g[2]);
-            sphere_finish<UV>(ps->o - c, ps->d, P.g[3], t, &rec);
-            rec.p = rec.p + c;
-        }
+    if (GENERAL || MEDIUM) {
+        SegCtx sc;
+        sc.rng_base = ps->g.base;
+        sc.segment = (uint32_t)ps->k;
+        sc.draws = 0;
+        sc.prims_tested = 0;
+        prim_hit<GENERAL, MEDIUM, UV, true>(L, prim, ps->o, ps->d, dot(ps->d, ps->d), sc, &rec);
+    } else {
+        const RtPrimGeo &G = L.prim_geo[prim];
+        V3 c = mk(G.g[0], G.g[1], G.g[2]);
+        sphere_finish<UV>(ps->o - c, ps->d, G.g[3], tv.best_t, &rec);
+        rec.p = rec.p + c;
     }
     V3 o2, d2, att, emit;
     const RtMaterial &M = L.materials[mat];

@@ -8,17 +8,25 @@
 
 #define RT_TILE_EDGE 8
 #define RT_TILE_PIXELS 64
-#define RT_STACK_DEPTH 24 /* traversal stack entries per lane; the builder bounds the tree depth to this */
+#define RT_STACK_DEPTH 24   /* traversal stack entries per lane; the builder bounds the tree depth to this */
+#define RT_MAX_HOISTED 4    /* scene-spanning prims tested up front instead of through the BVH */
+#define RT_JOB_SPP 32       /* samples per pixel in one job (job = one 8x8 tile x RT_JOB_SPP samples) */
 #define RT_NO_MATERIAL 0xFFFFFFFFu
+
+// 16-bit child references (stack entries pack one next to a truncated f32 tnear)
+#define RT_REF_LEAF 0x8000u       /* bit 15: leaf, low 15 bits = prim index; else inner node index */
+#define RT_REF_MAX 0x7FFFu
+#define RT_CUR_DONE 0x10000u      /* traversal finished, lane waits for the shade block */
+#define RT_CUR_DEAD 0x20000u      /* no work left for this lane */
 
 // primitive kinds (leaves of the acceleration structure)
 enum RtPrimKind : uint32_t {
-    RT_PRIM_SPHERE_T = 0, // Sprite<Sphere> whose transform is a pure translation: g = {cx, cy, cz, r}
-    RT_PRIM_SPHERE_M = 1, // Sprite<Sphere>, general matrix: g = {r}, xform
-    RT_PRIM_RECT_M = 2,   // Sprite<Rectangle> / TransformedGeometry<Rectangle>: g = {w, h}, xform
-    RT_PRIM_GROUP_M = 3,  // Sprite<BVH of TransformedGeometry<Rectangle>> (Cube): aux = first child, g[0] = count, xform
-    RT_PRIM_MEDIUM_T = 4, // Sprite<ConstantMedium<Sphere>>, translation: g = {cx, cy, cz, r}, aux = slot | density in g2
-    RT_PRIM_MEDIUM_M = 5, // general matrix: g = {r, density}, xform
+    RT_PRIM_SPHERE_T = 0, // Sprite<Sphere> whose transform is a pure translation: geo = {cx, cy, cz, r}
+    RT_PRIM_SPHERE_M = 1, // Sprite<Sphere>, general matrix: geo = {r}, xform
+    RT_PRIM_RECT_M = 2,   // Sprite<Rectangle> / TransformedGeometry<Rectangle>: geo = {w, h}, xform
+    RT_PRIM_GROUP_M = 3,  // Sprite<BVH of TransformedGeometry<Rectangle>> (Cube): aux = first child, geo[0] = count, xform
+    RT_PRIM_MEDIUM_T = 4, // Sprite<ConstantMedium<Sphere>>, translation: geo = {cx, cy, cz, r}, extra = {density}, aux = rng slot
+    RT_PRIM_MEDIUM_M = 5, // general matrix: geo = {r, density}, xform, aux = rng slot
 };
 
 enum RtMaterialKind : uint32_t {
@@ -31,23 +39,29 @@ enum RtMaterialKind : uint32_t {
 
 enum RtTextureKind : uint32_t { RT_TEX_SOLID = 0, RT_TEX_CHECKER = 1, RT_TEX_IMAGE = 2 };
 
-// BVH2 node with the two child boxes stored in the parent: one fetch decides both
-// children.  child >= 0: inner node index; child < 0: leaf, prim = ~child.
+// BVH2 node, binary32 CULLING boxes of both children stored in the parent, planes
+// interleaved as (child0, child1) pairs so one packed-f32 instruction handles both
+// children.  Boxes are rounded outward and padded (see rt_host.cpp): they only ever
+// decide which f64 primitive tests are skipped, never a result.
 struct alignas(16) RtNode {
-    double lo0[3], hi0[3];
-    double lo1[3], hi1[3];
-    int32_t child0, child1;
-    int32_t pad[6];
-}; // 128 B
+    float lo_x[2], lo_y[2], lo_z[2]; // [child]
+    float hi_x[2], hi_y[2], hi_z[2];
+    uint32_t child[2];               // 16-bit references, see RT_REF_*
+    uint32_t pad[2];
+}; // 64 B
 
-struct alignas(16) RtPrim {
+struct alignas(16) RtPrimMeta {
     uint32_t kind;
     uint32_t material; // RT_NO_MATERIAL = the reference's `material: None`
     uint32_t xform;    // index into xforms (kinds *_M)
     uint32_t aux;      // GROUP: first child prim; MEDIUM: rng slot
+}; // 16 B
+struct alignas(16) RtPrimGeo {
     double g[4];
-    double g2[2];      // MEDIUM_T: {density, -}; padding otherwise
-}; // 64 B
+}; // 32 B
+struct alignas(16) RtPrimExtra {
+    double e[2];
+}; // 16 B
 
 // rows 0..2 of M and M^-1 (row-major, 4 coefficients each: x y z w); row 3 of a
 // Mat4 never reaches a Vec3 (src/vec4.rs:97-103 drops w).
@@ -81,26 +95,36 @@ struct RtCameraD {
 };
 
 struct RtCounters {
-    unsigned long long samples, segments, nodes_visited, prims_tested, rng_draws, wave_iterations, lane_iterations;
+    unsigned long long samples, segments, nodes_visited, prims_tested, rng_draws;
+    // scheduling statistics of the wave-vote loop: executions of each block and
+    // the lanes that were active in them (lane / (64 * wave) = SIMD utilisation)
+    unsigned long long node_wave, node_lane, leaf_wave, leaf_lane, shade_wave, shade_lane;
 };
 
 // kernel arguments (passed by value)
 struct RtLaunch {
     const RtNode *nodes;
-    const RtPrim *prims;
+    const RtPrimMeta *prim_meta;
+    const RtPrimGeo *prim_geo;
+    const RtPrimExtra *prim_extra;
     const RtXform *xforms;
     const RtMaterial *materials;
     const RtTexture *textures;
     const uint8_t *image_blob;
-    int32_t root; // node index, or ~prim when the scene is a single primitive
+    uint32_t root;      // 16-bit reference of the BVH root, or RT_CUR_DONE when every prim is hoisted
+    int32_t n_hoisted;  // prims [0, n_hoisted) are tested directly for every segment
     int32_t n_prims;
     RtCameraD cam;
     int32_t width, height, spp, max_depth;
     uint64_t seed_mix; // rt_mix64(seed)
     int32_t tiles_x, tiles_y;
     int32_t shard_index, shard_count, n_owned_tiles;
-    double *out;            // packed owned tiles: [k][64][3]
-    RtCounters *counters;   // may be null
+    // this pass: samples [s0, s0 + s_count) of every owned pixel
+    int32_t s0, s_count;
+    int32_t jobs_per_tile, n_jobs;
+    unsigned int *job_counter; // zeroed before the launch
+    double *samples;           // per-sample radiance of this pass: [owned tile][s - s0][pixel][3]
+    RtCounters *counters;      // may be null
 };
 
 #endif

@@ -12,18 +12,17 @@
 
 namespace {
 struct ArrayStack {
-    int32_t v[RT_STACK_DEPTH];
-    int sp = 0;
+    uint32_t v[RT_STACK_DEPTH];
     int high_water = 0;
-    void reset() { sp = 0; }
-    void push(int32_t x) {
+    void push(int32_t &sp, uint32_t x) {
         v[sp++] = x;
         if (sp > high_water) high_water = sp;
     }
-    int32_t pop() { return v[--sp]; }
-    bool empty() const { return sp == 0; }
+    uint32_t pop(int32_t &sp) { return v[--sp]; }
 };
 
+// One lane's state machine run to completion: the wave-vote loop of render_kernel only
+// decides WHEN a lane's next step runs, never what it computes.
 template <bool G, bool M, bool T, bool LENS>
 void run(const RtLaunch &L, int x0, int y0, int x1, int y1, double *out, double *samples_out, int sx, int sy,
          unsigned long long *cnt, int *stack_high) {
@@ -33,10 +32,20 @@ void run(const RtLaunch &L, int x0, int y0, int x1, int y1, double *out, double 
             rtl::V3 acc = rtl::mk(0, 0, 0);
             for (int s = 0; s < L.spp; ++s) {
                 rtl::PathState ps;
+                rtl::Trav tv;
                 rtl::start_sample<LENS>(L, (uint32_t)x, (uint32_t)y, (uint32_t)s, &ps);
                 for (;;) {
                     cnt[1]++;
-                    if (rtl::advance_segment<G, M, T>(L, &ps, st, &cnt[2], &cnt[3])) break;
+                    rtl::begin_segment<G, M, T>(L, &ps, tv, st, &cnt[3]);
+                    while (tv.cur != RT_CUR_DONE) {
+                        if (tv.cur < RT_REF_LEAF) {
+                            cnt[2]++;
+                            rtl::trav_node_step(L, tv, st);
+                        } else {
+                            rtl::leaf_step<G, M, T>(L, &ps, tv, st, &cnt[3]);
+                        }
+                    }
+                    if (rtl::finish_segment<G, M, T>(L, &ps, tv)) break;
                 }
                 cnt[0]++;
                 cnt[4] += ps.g.draws;
@@ -64,12 +73,15 @@ extern "C" int lane_emul_render(rt_scene *s, const rt_camera *cam, int W, int H,
     RtLaunch L;
     std::memset(&L, 0, sizeof L);
     L.nodes = s->flat.nodes.data();
-    L.prims = s->flat.prims.data();
+    L.prim_meta = s->flat.prim_meta.data();
+    L.prim_geo = s->flat.prim_geo.data();
+    L.prim_extra = s->flat.prim_extra.data();
     L.xforms = s->flat.xforms.data();
     L.materials = s->flat.materials.data();
     L.textures = s->flat.textures.data();
     L.image_blob = s->flat.image_blob.data();
     L.root = s->flat.root;
+    L.n_hoisted = s->flat.n_hoisted;
     L.n_prims = s->flat.n_leaf_prims;
     for (int i = 0; i < 3; ++i) {
         L.cam.eye[i] = cam->eye[i];

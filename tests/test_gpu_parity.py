@@ -57,5 +57,6 @@ def test_counters_and_max_depth_zero(rt, scenes, gpu_device):
     img, cnt = sc.render(cam, W, H, 2, 50, seed=1, counters=True)
     assert cnt["samples"] == W * H * 2
     assert cnt["segments"] >= cnt["samples"]
+    assert cnt["node_lane"] == cnt["nodes_visited"] and cnt["shade_wave"] > 0
     assert np.array_equal(img, sc.render(cam, W, H, 2, 50, seed=1))
     assert np.array_equal(sc.render(cam, W, H, 2, 0, seed=1), np.zeros((H, W, 3)))
