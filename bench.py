@@ -162,7 +162,9 @@ def main():
                          "segments_per_sample": cnt["segments"] / ns, "nodes_per_sample": cnt["nodes_visited"] / ns,
                          "prims_per_sample": cnt["prims_tested"] / ns,
                          "simd_utilisation": {b: cnt[b + "_lane"] / max(1, 64 * cnt[b + "_wave"]) for b in ("node", "leaf", "shade")},
-                         "block_executions_per_sample": {b: cnt[b + "_wave"] * 64 / ns for b in ("node", "leaf", "shade")}},
+                         "block_executions_per_sample": {b: cnt[b + "_wave"] * 64 / ns for b in ("node", "leaf", "shade")},
+                         "block_cycle_share": {b: cnt[b + "_cycles"] / max(1, cnt["node_cycles"] + cnt["leaf_cycles"] + cnt["shade_cycles"])
+                                               for b in ("node", "leaf", "shade", "finish", "refill", "begin")}},
             "wall_s": dt, "last_kernel_ms": last_kernel_ms,
         }
         if not a.no_cpu_baseline and world == 1:

@@ -144,6 +144,8 @@ typedef struct rt_counters {
     /* executions of each block of the wave-vote loop and the lanes active in them:
      * lane / (64 * wave) is the SIMD utilisation of that block */
     uint64_t node_wave, node_lane, leaf_wave, leaf_lane, shade_wave, shade_lane;
+    /* shader-clock cycles spent in each block, summed over waves (diagnostic) */
+    uint64_t node_cycles, leaf_cycles, shade_cycles, finish_cycles, refill_cycles, begin_cycles;
 } rt_counters;
 
 /* Render into host memory: out_rgb[(y*W + x)*3 + c].  With shard_count > 1 only

@@ -21,7 +21,8 @@ from pathlib import Path
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "lib" / "librt_mi355x.so"
+# RT_MI355X_LIB: alternative build of the same library (A/B tuning experiments only)
+LIB_PATH = Path(os.environ.get("RT_MI355X_LIB") or (_HERE / "lib" / "librt_mi355x.so"))
 
 RT_TILE = 8
 RT_FLAG_COUNTERS = 1
@@ -46,7 +47,9 @@ class rt_render_params(C.Structure):
 
 class rt_counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "segments", "nodes_visited", "prims_tested", "rng_draws",
-                                            "node_wave", "node_lane", "leaf_wave", "leaf_lane", "shade_wave", "shade_lane")]
+                                            "node_wave", "node_lane", "leaf_wave", "leaf_lane", "shade_wave", "shade_lane",
+                                            "node_cycles", "leaf_cycles", "shade_cycles", "finish_cycles", "refill_cycles",
+                                            "begin_cycles")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -20,10 +20,13 @@
 #include <string>
 #include <vector>
 
-extern "C" int rt_launch_render(const RtLaunch *L, unsigned features, int lens, int count, int blocks, void *stream);
+extern "C" int rt_launch_render(const RtLaunch *L, unsigned features, int lens, int count, int ldsnodes, int blocks,
+                                unsigned lds_bytes, void *stream);
 extern "C" int rt_launch_reduce(const double *samples, double *tiles, int n_owned_tiles, int s_count, int first_pass, int last_pass,
                                 int spp, int width, int height, int shard_index, int shard_count, void *stream);
-extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int *blocks_per_cu, int *n_cu);
+extern "C" int rt_kernel_block_size(void);
+extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int ldsnodes, unsigned lds_bytes, int *blocks_per_cu,
+                                    int *n_cu);
 extern "C" int rt_launch_unpack(const double *gathered, int tiles_per_shard, int shard_count, int width, int height,
                                 double *image, void *stream);
 extern "C" int rt_launch_probe_math(const double *a, const double *b, int n, double *out_sqrt, double *out_div, void *stream);
@@ -247,6 +250,8 @@ static void fill_launch(const rt_scene *s, const rt_camera *cam, const rt_render
     L->materials = (const RtMaterial *)s->d_materials;
     L->textures = (const RtTexture *)s->d_textures;
     L->image_blob = (const uint8_t *)s->d_blob;
+    L->n_nodes = (int)s->flat.nodes.size();
+    L->stack_entries = std::min(RT_STACK_DEPTH, s->flat.max_depth + 1);
     L->root = s->flat.root;
     L->n_hoisted = s->flat.n_hoisted;
     L->n_prims = s->flat.n_leaf_prims;
@@ -323,12 +328,21 @@ int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_render_pa
     const bool count = (p->flags & RT_FLAG_COUNTERS) && d_counters;
     const unsigned feat = kernel_features(s);
     const int lens = cam->lens_radius != 0.0;
-    int per_cu = 0, n_cu = 0;
-    int rc = rt_persistent_blocks(feat, lens, count, &per_cu, &n_cu);
-    if (rc != 0) return hip_fail((hipError_t)rc, "occupancy query");
-    if (per_cu < 1) per_cu = 1;
     RtLaunch L;
     fill_launch(s, cam, p, n_owned, &L);
+    // dynamic LDS: the traversal stack, plus a copy of the node array when three workgroups
+    // of it still fit the CU's 160 KiB (book-one: 31 KB of nodes + 12 KB of stack)
+    const unsigned block = (unsigned)rt_kernel_block_size();
+    const unsigned stack_bytes = (unsigned)L.stack_entries * block * 4u;
+    const unsigned node_bytes = (unsigned)(s->flat.nodes.size() * sizeof(RtNode));
+    const char *no_lds = std::getenv("RT_NO_LDS_NODES");
+    // keep 16 waves per CU resident: (1024 / block) workgroups, each with its own node copy
+    const int ldsnodes = node_bytes > 0 && (1024u / block) * (stack_bytes + node_bytes) <= 160u * 1024u && !(no_lds && *no_lds == '1');
+    const unsigned lds_bytes = stack_bytes + (ldsnodes ? node_bytes : 0u);
+    int per_cu = 0, n_cu = 0;
+    int rc = rt_persistent_blocks(feat, lens, count, ldsnodes, lds_bytes, &per_cu, &n_cu);
+    if (rc != 0) return hip_fail((hipError_t)rc, "occupancy query");
+    if (per_cu < 1) per_cu = 1;
     L.samples = (double *)s->d_samples;
     L.counters = count ? (RtCounters *)d_counters : nullptr;
     const int n_pass = (p->spp + chunk - 1) / chunk;
@@ -344,10 +358,12 @@ int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_render_pa
         const long long n_jobs = (long long)L.jobs_per_tile * n_owned;
         if (n_jobs > 0x7FFFFFFFll) return fail(RT_ERR_INVALID, "too many jobs in one pass");
         L.n_jobs = (int)n_jobs;
-        const int blocks = (int)std::min<long long>((long long)per_cu * n_cu, (n_jobs + 3) / 4 > 0 ? (n_jobs + 3) / 4 : 1);
+        const long long waves_per_block = block / 64;
+        const long long want = (n_jobs + waves_per_block - 1) / waves_per_block;
+        const int blocks = (int)std::min<long long>((long long)per_cu * n_cu, want > 0 ? want : 1);
         HIP_TRY(hipMemsetAsync(s->d_job_counter, 0, sizeof(unsigned int), st));
         HIP_TRY(hipEventRecord(s->events[(size_t)(2 * pass)], st));
-        rc = rt_launch_render(&L, feat, lens, count, blocks, stream);
+        rc = rt_launch_render(&L, feat, lens, count, ldsnodes, blocks, lds_bytes, stream);
         if (rc != 0) return hip_fail((hipError_t)rc, "render_kernel launch");
         HIP_TRY(hipEventRecord(s->events[(size_t)(2 * pass + 1)], st));
         s->events_used = 2 * (pass + 1);
@@ -422,6 +438,12 @@ int rt_render(rt_scene *s, const rt_camera *cam, const rt_render_params *p, doub
             counters->leaf_lane = c.leaf_lane;
             counters->shade_wave = c.shade_wave;
             counters->shade_lane = c.shade_lane;
+            counters->node_cycles = c.node_cycles;
+            counters->leaf_cycles = c.leaf_cycles;
+            counters->shade_cycles = c.shade_cycles;
+            counters->finish_cycles = c.finish_cycles;
+            counters->refill_cycles = c.refill_cycles;
+            counters->begin_cycles = c.begin_cycles;
         }
     }
     (void)hipFree(d_out);

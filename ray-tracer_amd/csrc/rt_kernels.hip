@@ -34,18 +34,20 @@
 #include "rt_lane.h"
 #include "rt_types.h"
 
-#define RT_BLOCK 256 /* 4 waves per workgroup */
+#ifndef RT_BLOCK
+#define RT_BLOCK 512 /* threads per workgroup: 8 waves share one LDS copy of the node array */
+#endif
 
 // vote thresholds (lanes).  A block runs when at least this many lanes wait for
 // it, or when no cheaper block has work.
 #ifndef RT_VOTE_SHADE
-#define RT_VOTE_SHADE 24
+#define RT_VOTE_SHADE 40
 #endif
 #ifndef RT_VOTE_LEAF
-#define RT_VOTE_LEAF 16
+#define RT_VOTE_LEAF 32
 #endif
 #ifndef RT_NODE_KEEP
-#define RT_NODE_KEEP 20
+#define RT_NODE_KEEP 40
 #endif
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 4
@@ -70,11 +72,25 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) { // set 
 }
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-template <bool GENERAL, bool MEDIUM, bool TEXTURED, bool LENS, bool COUNT>
+// Dynamic LDS: [stack_entries][RT_BLOCK] traversal stack, then (LDSNODES) a copy of the
+// whole node array: node steps are a dependent pointer chase, and an LDS read returns
+// in ~1/4 of an L2 hit.
+extern __shared__ __attribute__((aligned(16))) unsigned char rt_lds[];
+
+template <bool GENERAL, bool MEDIUM, bool TEXTURED, bool LENS, bool COUNT, bool LDSNODES>
 __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void render_kernel(const RtLaunch L) {
-    __shared__ uint32_t stack_mem[RT_STACK_DEPTH * RT_BLOCK];
+    uint32_t *stack_mem = reinterpret_cast<uint32_t *>(rt_lds);
     LdsStack st;
     st.base = stack_mem + threadIdx.x;
+    const RtNode *nodes = L.nodes;
+    if (LDSNODES) {
+        uint4 *dst = reinterpret_cast<uint4 *>(rt_lds + (size_t)L.stack_entries * RT_BLOCK * sizeof(uint32_t));
+        const uint4 *src = reinterpret_cast<const uint4 *>(L.nodes);
+        const int n16 = L.n_nodes * (int)(sizeof(RtNode) / 16);
+        for (int i = (int)threadIdx.x; i < n16; i += RT_BLOCK) dst[i] = src[i];
+        __syncthreads();
+        nodes = reinterpret_cast<const RtNode *>(dst);
+    }
 
     rtl::PathState ps;
     rtl::Trav tv;
@@ -91,6 +107,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void render_kernel(const
 
     unsigned long long c_nodes = 0, c_prims = 0, c_segs = 0, c_draws = 0, c_samples = 0;
     unsigned long long c_nw = 0, c_nl = 0, c_lw = 0, c_ll = 0, c_sw = 0, c_sl = 0;
+    unsigned long long t_n = 0, t_l = 0, t_s = 0, t_fin = 0, t_ref = 0, t_beg = 0, t0 = 0, t1 = 0;
+#define RT_STAMP(v) do { if (COUNT) v = __builtin_amdgcn_s_memtime(); } while (0)
     const bool counting_lane = COUNT && (threadIdx.x & 63) == 0;
 
     for (;;) {
@@ -107,15 +125,17 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void render_kernel(const
                 ++c_sw;
                 c_sl += (unsigned long long)nS;
             }
+            RT_STAMP(t0);
             bool need = false;
             if (is_done) {
                 if (has_path) {
                     if (COUNT) ++c_segs;
-                    if (rtl::finish_segment<GENERAL, MEDIUM, TEXTURED>(L, &ps, tv)) {
+                    rtl::V3 rad;
+                    if (rtl::finish_segment<GENERAL, MEDIUM, TEXTURED>(L, &ps, tv, &rad)) {
                         double *o = L.samples + (size_t)slot * 3;
-                        o[0] = ps.Lsum.x;
-                        o[1] = ps.Lsum.y;
-                        o[2] = ps.Lsum.z;
+                        o[0] = rad.x;
+                        o[1] = rad.y;
+                        o[2] = rad.z;
                         has_path = false;
                         if (COUNT) {
                             c_draws += ps.g.draws;
@@ -125,6 +145,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void render_kernel(const
                 }
                 need = !has_path;
             }
+            RT_STAMP(t1);
+            t_fin += t1 - t0;
             // refill: lanes without a path take the next samples of the job queue.  Executed by the
             // whole wave (wave-uniform control flow) so the job state stays identical in every lane.
             for (;;) {
@@ -167,21 +189,29 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void render_kernel(const
                 job_next += take;
                 job_left -= take;
             }
+            RT_STAMP(t0);
+            t_ref += t0 - t1;
             if (is_done) {
                 if (has_path)
                     rtl::begin_segment<GENERAL, MEDIUM, TEXTURED>(L, &ps, tv, st, &c_prims);
                 else
                     tv.cur = RT_CUR_DEAD;
             }
+            RT_STAMP(t1);
+            t_beg += t1 - t0;
         } else if (nL >= RT_VOTE_LEAF || nN == 0) {
             // ---------------- leaf block ----------------
             if (COUNT && counting_lane) {
                 ++c_lw;
                 c_ll += (unsigned long long)nL;
             }
+            RT_STAMP(t0);
             if (is_leaf) rtl::leaf_step<GENERAL, MEDIUM, TEXTURED>(L, &ps, tv, st, &c_prims);
+            RT_STAMP(t1);
+            t_l += t1 - t0;
         } else {
             // ---------------- node block ----------------
+            RT_STAMP(t0);
             for (;;) {
                 const bool at_node = tv.cur < RT_REF_LEAF;
                 const int n = __popcll(__ballot(at_node));
@@ -192,10 +222,12 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void render_kernel(const
                 }
                 if (at_node) {
                     if (COUNT) ++c_nodes;
-                    rtl::trav_node_step(L, tv, st);
+                    rtl::trav_node_step(nodes, tv, st);
                 }
                 if (n < RT_NODE_KEEP) break;
             }
+            RT_STAMP(t1);
+            t_n += t1 - t0;
         }
     }
 
@@ -212,6 +244,12 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void render_kernel(const
             atomicAdd(&L.counters->leaf_lane, c_ll);
             atomicAdd(&L.counters->shade_wave, c_sw);
             atomicAdd(&L.counters->shade_lane, c_sl);
+            atomicAdd(&L.counters->node_cycles, t_n);
+            atomicAdd(&L.counters->leaf_cycles, t_l);
+            atomicAdd(&L.counters->shade_cycles, t_fin + t_ref + t_beg);
+            atomicAdd(&L.counters->finish_cycles, t_fin);
+            atomicAdd(&L.counters->refill_cycles, t_ref);
+            atomicAdd(&L.counters->begin_cycles, t_beg);
         }
     }
 }
@@ -278,34 +316,59 @@ __global__ void probe_math_kernel(const double *a, const double *b, int n, doubl
     out_div[i] = a[i] / b[i];
 }
 
+// ---- dispatch over the template instantiations ----
+typedef void (*KernelFn)(const RtLaunch);
+
 template <bool GENERAL, bool MEDIUM, bool TEXTURED>
-hipError_t launch3(const RtLaunch &L, bool lens, bool count, int blocks, hipStream_t stream) {
-    dim3 g((unsigned)blocks), b(RT_BLOCK);
+KernelFn pick3(bool lens, bool count, bool ldsnodes) {
+#define RT_PICK(LN, C, LD) return render_kernel<GENERAL, MEDIUM, TEXTURED, LN, C, LD>
     if (lens) {
-        if (count)
-            hipLaunchKernelGGL((render_kernel<GENERAL, MEDIUM, TEXTURED, true, true>), g, b, 0, stream, L);
-        else
-            hipLaunchKernelGGL((render_kernel<GENERAL, MEDIUM, TEXTURED, true, false>), g, b, 0, stream, L);
+        if (count) {
+            if (ldsnodes) RT_PICK(true, true, true); else RT_PICK(true, true, false);
+        } else {
+            if (ldsnodes) RT_PICK(true, false, true); else RT_PICK(true, false, false);
+        }
     } else {
-        if (count)
-            hipLaunchKernelGGL((render_kernel<GENERAL, MEDIUM, TEXTURED, false, true>), g, b, 0, stream, L);
-        else
-            hipLaunchKernelGGL((render_kernel<GENERAL, MEDIUM, TEXTURED, false, false>), g, b, 0, stream, L);
+        if (count) {
+            if (ldsnodes) RT_PICK(false, true, true); else RT_PICK(false, true, false);
+        } else {
+            if (ldsnodes) RT_PICK(false, false, true); else RT_PICK(false, false, false);
+        }
     }
-    return hipGetLastError();
+#undef RT_PICK
+}
+KernelFn pick(unsigned features, bool lens, bool count, bool ldsnodes) {
+    return features == 0u ? pick3<false, false, false>(lens, count, ldsnodes) : pick3<true, true, true>(lens, count, ldsnodes);
 }
 
 } // namespace
 
-// feature bits: 1 = general prims, 2 = media, 4 = textured.  `blocks` persistent workgroups.
-extern "C" int rt_launch_render(const RtLaunch *L, unsigned features, int lens, int count, int blocks, void *stream) {
-    hipStream_t s = (hipStream_t)stream;
-    hipError_t e;
-    if (features == 0u)
-        e = launch3<false, false, false>(*L, lens != 0, count != 0, blocks, s);
-    else
-        e = launch3<true, true, true>(*L, lens != 0, count != 0, blocks, s);
+// feature bits: 1 = general prims, 2 = media, 4 = textured.  `blocks` persistent workgroups,
+// `lds_bytes` of dynamic LDS (stack + optional node copy).
+extern "C" int rt_launch_render(const RtLaunch *L, unsigned features, int lens, int count, int ldsnodes, int blocks,
+                                unsigned lds_bytes, void *stream) {
+    KernelFn k = pick(features, lens != 0, count != 0, ldsnodes != 0);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(RT_BLOCK), lds_bytes, (hipStream_t)stream, *L);
+    hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int rt_kernel_block_size(void) { return RT_BLOCK; }
+
+// occupancy-derived size of the persistent grid
+extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int ldsnodes, unsigned lds_bytes, int *blocks_per_cu,
+                                    int *n_cu) {
+    KernelFn k = pick(features, lens != 0, count != 0, ldsnodes != 0);
+    int per_cu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, RT_BLOCK, lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return (int)e;
+    if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return (int)e;
+    *blocks_per_cu = per_cu;
+    *n_cu = prop.multiProcessorCount;
+    return 0;
 }
 
 extern "C" int rt_launch_reduce(const double *samples, double *tiles, int n_owned_tiles, int s_count, int first_pass, int last_pass,
@@ -335,32 +398,3 @@ extern "C" int rt_launch_probe_math(const double *a, const double *b, int n, dou
     return e == hipSuccess ? 0 : (int)e;
 }
 
-// occupancy-derived size of the persistent grid
-extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int *blocks_per_cu, int *n_cu) {
-    int per_cu = 0;
-    hipError_t e;
-#define RT_OCC(G, M, T, LN, C) \
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)render_kernel<G, M, T, LN, C>, RT_BLOCK, 0)
-    if (features == 0u) {
-        if (lens) {
-            if (count) RT_OCC(false, false, false, true, true); else RT_OCC(false, false, false, true, false);
-        } else {
-            if (count) RT_OCC(false, false, false, false, true); else RT_OCC(false, false, false, false, false);
-        }
-    } else {
-        if (lens) {
-            if (count) RT_OCC(true, true, true, true, true); else RT_OCC(true, true, true, true, false);
-        } else {
-            if (count) RT_OCC(true, true, true, false, true); else RT_OCC(true, true, true, false, false);
-        }
-    }
-#undef RT_OCC
-    if (e != hipSuccess) return (int)e;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if ((e = hipGetDevice(&dev)) != hipSuccess) return (int)e;
-    if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return (int)e;
-    *blocks_per_cu = per_cu;
-    *n_cu = prop.multiProcessorCount;
-    return 0;
-}

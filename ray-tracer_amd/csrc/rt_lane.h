@@ -396,12 +396,14 @@ RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack
     tv.cur = L.root;
 }
 
-// one inner-node step (tv.cur is an inner node reference)
+// one inner-node step (tv.cur is an inner node reference).  `nodes` is the node array
+// (LDS copy or global).  Branch-free up to the push/pop so the whole 64-byte node,
+// child references included, is fetched by one batch of loads.
 template <class Stack>
-RT_HD void trav_node_step(const RtLaunch &L, Trav &tv, Stack &st) {
-    const RtNode &N = L.nodes[tv.cur];
+RT_HD void trav_node_step(const RtNode *nodes, Trav &tv, Stack &st) {
+    const RtNode &N = nodes[tv.cur];
+    const uint32_t c0 = N.child[0], c1 = N.child[1];
     float tmin[2], tmax[2];
-    bool hit[2];
     for (int c = 0; c < 2; ++c) {
         // fminf / fmaxf ignore a NaN operand (0 * inf planes), like the reference's selects
         const float ax = fmaf(N.lo_x[c], tv.idx, tv.nx), bx = fmaf(N.hi_x[c], tv.idx, tv.nx);
@@ -412,24 +414,19 @@ RT_HD void trav_node_step(const RtLaunch &L, Trav &tv, Stack &st) {
         const float cz = fmaf(N.lo_z[c], tv.idz, tv.fz), dz = fmaf(N.hi_z[c], tv.idz, tv.fz);
         tmin[c] = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
         tmax[c] = fminf(fminf(fmaxf(cx, dx), fmaxf(cy, dy)), fminf(fmaxf(cz, dz), tv.best32));
-        hit[c] = tmin[c] <= tmax[c] * 1.000001f; // slack for the rounding of the slab arithmetic itself
     }
-    if (hit[0] && hit[1]) {
-        const int nearc = tmin[1] < tmin[0] ? 1 : 0;
-        const int farc = 1 - nearc;
-        st.push(tv.sp, (f32_bits(tmin[farc]) & 0xFFFF0000u) | N.child[farc]);
-        tv.cur = N.child[nearc];
-        return;
-    }
-    if (hit[0]) {
-        tv.cur = N.child[0];
-        return;
-    }
-    if (hit[1]) {
-        tv.cur = N.child[1];
-        return;
-    }
-    trav_pop(tv, st);
+    // slack for the rounding of the slab arithmetic itself
+    const bool h0 = tmin[0] <= tmax[0] * 1.000001f, h1 = tmin[1] <= tmax[1] * 1.000001f;
+    const bool one_first = tmin[1] < tmin[0];
+    const bool both = h0 && h1;
+    const uint32_t first = both ? (one_first ? c1 : c0) : (h0 ? c0 : c1);
+    const uint32_t second = one_first ? c0 : c1;
+    const float second_t = one_first ? tmin[0] : tmin[1];
+    if (both) st.push(tv.sp, (f32_bits(second_t) & 0xFFFF0000u) | second);
+    if (h0 || h1)
+        tv.cur = first;
+    else
+        trav_pop(tv, st);
 }
 
 // one leaf step (tv.cur is a leaf reference): binary64 primitive test, then pop
@@ -474,13 +471,27 @@ RT_HD V3 texture_value(const RtLaunch &L, uint32_t tex, double u, double v) {
     return mk(0.0, 0.0, 0.0);
 }
 
-RT_HD double schlick(double theta, double n1, double n2) { // src/material.rs:140-143
-    double r0 = pow((n1 - n2) / (n1 + n2), 2.0);
-    return r0 + (1.0 - r0) * pow(1.0 - cos(theta), 5.0);
+// Dielectric::schlickReflectionProbability(theta = acos(c), n1, n2) (src/material.rs:140-143)
+// evaluated from c directly: powf(2) -> q*q, cos(acos(c)) -> c, powf(5) by multiplication.
+// Each substitution moves the probability by a few ulp at most (the reference's own libm
+// calls are only faithful to that level, and the value is only ever compared with a
+// uniform draw).  acos(c) is NaN for |c| > 1, which makes the reference refract: kept.
+RT_HD bool schlick_reflects(double c, double n1, double n2, double u) {
+    if (!(c >= -1.0 && c <= 1.0)) return false; // u < NaN
+    double q = (n1 - n2) / (n1 + n2);
+    double r0 = q * q;
+    double y = 1.0 - c;
+    double y2 = y * y;
+    double y5 = y2 * y2 * y;
+    return u < r0 + (1.0 - r0) * y5;
 }
 
 // Material::scatter + emitted for the hit material (src/material.rs:61-69,99-118,
 // 147-192,291-297,318-325).  Returns true if the path continues with (o, d).
+// The per-material branches only build the un-normalised direction; the rejection
+// sampler and the final normalisation are shared, so a wave with mixed materials
+// executes each of them once.  Per lane the operations (and the random draws) are
+// exactly those of its own material's scatter().
 template <bool TEXTURED>
 RT_HD bool shade(const RtLaunch &L, const RtMaterial &M, const Rec &rec, V3 d_in, Rng &g, V3 *o_out, V3 *d_out, V3 *att,
                  V3 *emit) {
@@ -488,64 +499,73 @@ RT_HD bool shade(const RtLaunch &L, const RtMaterial &M, const Rec &rec, V3 d_in
     V3 tex = ld3(M.rgb);
     if (TEXTURED && !M.solid) tex = texture_value(L, M.tex, rec.u, rec.v);
     *o_out = rec.p;
-    switch (M.kind) {
-    case RT_MAT_LAMBERTIAN:
-        *d_out = normalized(rec.n + random_in_unit_sphere(g));
-        *att = tex;
-        return true;
-    case RT_MAT_METAL: {
-        if (dot(d_in, rec.n) < 0.0) {
-            V3 refl = reflected(normalized(d_in), rec.n);
-            if (M.param == 0.0)
-                *d_out = refl;
-            else
-                *d_out = normalized(refl + random_in_unit_sphere(g) * M.param);
-            *att = tex;
-            return true;
-        }
-        return false; // hit from behind: absorbed (quirk Q6)
+    *att = tex;
+    const uint32_t kind = M.kind;
+    if (kind == RT_MAT_DIFFUSE_LIGHT) {
+        *emit = tex;
+        return false;
     }
-    case RT_MAT_DIELECTRIC: {
+    const double dn = dot(d_in, rec.n);
+    if (kind == RT_MAT_METAL && !(dn < 0.0)) return false; // hit from behind: absorbed (quirk Q6)
+
+    // d.normalized() for the specular materials
+    V3 uvn = d_in;
+    if (kind == RT_MAT_METAL || kind == RT_MAT_DIELECTRIC) uvn = normalized(d_in);
+    // randomInUnitSphere() for the diffuse ones and fuzzy metal
+    V3 ball = mk(0.0, 0.0, 0.0);
+    if (kind == RT_MAT_LAMBERTIAN || kind == RT_MAT_ISOTROPIC || (kind == RT_MAT_METAL && M.param != 0.0))
+        ball = random_in_unit_sphere(g);
+
+    V3 v = ball; // Isotropic: randomInUnitSphere().normalized()
+    bool norm = true;
+    if (kind == RT_MAT_LAMBERTIAN) {
+        v = rec.n + ball;
+    } else if (kind == RT_MAT_METAL) {
+        V3 refl = reflected(uvn, rec.n);
+        if (M.param == 0.0) {
+            v = refl;
+            norm = false;
+        } else {
+            v = refl + ball * M.param;
+        }
+    } else if (kind == RT_MAT_DIELECTRIC) {
         *att = mk(1.0, 1.0, 1.0);
         double ratio;
         V3 normal = rec.n;
-        if (dot(d_in, rec.n) < 0.0) {
+        if (dn < 0.0) {
             ratio = 1.0 / M.param;
         } else {
             ratio = M.param;
             normal = -normal;
         }
-        // Vec3::refracted, src/vec3.rs:113-124
-        V3 uvn = normalized(d_in);
+        // Vec3::refracted, src/vec3.rs:113-124 (built from the UN-normalised direction)
         double dt = dot(uvn, normal);
         double disc = 1.0 - ratio * ratio * (1.0 - dt * dt);
         if (disc > 0.0) {
             V3 refr = (d_in - normal * dt) * ratio - normal * sqrt(disc);
-            double theta = acos(-dot(d_in, normal));
             double u = rng_range01(g);
-            if (u < schlick(theta, ratio, 1.0))
-                *d_out = reflected(d_in, rec.n); // about the un-flipped normal (quirk Q7)
-            else
-                *d_out = normalized(refr);
+            if (schlick_reflects(-dot(d_in, normal), ratio, 1.0, u)) {
+                v = reflected(d_in, rec.n); // about the un-flipped normal (quirk Q7)
+                norm = false;
+            } else {
+                v = refr;
+            }
         } else {
-            *d_out = reflected(d_in, normal); // total internal reflection: no draw
+            v = reflected(d_in, normal); // total internal reflection: no draw
+            norm = false;
         }
-        return true;
     }
-    case RT_MAT_DIFFUSE_LIGHT:
-        *emit = tex;
-        return false;
-    case RT_MAT_ISOTROPIC:
-        *d_out = normalized(random_in_unit_sphere(g));
-        *att = tex;
-        return true;
-    }
-    return false;
+    V3 vn = normalized(v);
+    *d_out = norm ? vn : v;
+    return true;
 }
 
 // ---------------------------------------------------------------- path state
 struct PathState {
-    V3 o, d, T, Lsum;
+    // Only DiffuseLight emits and it never scatters (src/material.rs:17-20,291-297), so the
+    // iterative sum L = sum_k T_k * e_k has at most one non-zero term, the last one:
+    // the sample's radiance is T * emitted at the terminal hit, else 0.
+    V3 o, d, T;
     Rng g;
     int32_t k; // segments traced so far
 };
@@ -562,7 +582,6 @@ RT_HD void start_sample(const RtLaunch &L, uint32_t x, uint32_t y, uint32_t s, P
     double v = ((double)y + rng_range01(ps->g)) / (double)L.height;
     camera_ray<LENS>(L.cam, u, v, ps->g, &ps->o, &ps->d);
     ps->T = mk(1.0, 1.0, 1.0);
-    ps->Lsum = mk(0.0, 0.0, 0.0);
     ps->k = 0;
 }
 
@@ -592,10 +611,12 @@ RT_HD void leaf_step(const RtLaunch &L, PathState *ps, Trav &tv, Stack &st, unsi
 
 // The traversal of this segment is finished (tv.cur == RT_CUR_DONE): shade it.
 // render::color, src/render.rs:5-29, in its iterative form
-// L = sum_k (prod_{j<k} att_j) * e_k.  Returns true when the sample is finished.
+// L = sum_k (prod_{j<k} att_j) * e_k.  Returns true when the sample is finished, with its
+// radiance in *radiance.
 template <bool GENERAL, bool MEDIUM, bool TEXTURED>
-RT_HD bool finish_segment(const RtLaunch &L, PathState *ps, const Trav &tv) {
+RT_HD bool finish_segment(const RtLaunch &L, PathState *ps, const Trav &tv, V3 *radiance) {
     constexpr bool UV = TEXTURED;
+    *radiance = mk(0.0, 0.0, 0.0);
     if (tv.best_prim == 0xFFFFFFFFu) return true; // background is black (src/render.rs:21-28)
     const uint32_t prim = tv.best_prim;
     const uint32_t mat = L.prim_meta[prim].material;
@@ -617,7 +638,7 @@ RT_HD bool finish_segment(const RtLaunch &L, PathState *ps, const Trav &tv) {
     V3 o2, d2, att, emit;
     const RtMaterial &M = L.materials[mat];
     const bool cont = shade<TEXTURED>(L, M, rec, ps->d, ps->g, &o2, &d2, &att, &emit);
-    if (M.kind == RT_MAT_DIFFUSE_LIGHT) ps->Lsum = ps->Lsum + ps->T * emit;
+    if (M.kind == RT_MAT_DIFFUSE_LIGHT) *radiance = ps->T * emit;
     if (!cont) return true;
     ps->T = ps->T * att;
     ps->o = o2;

@@ -99,6 +99,8 @@ struct RtCounters {
     // scheduling statistics of the wave-vote loop: executions of each block and
     // the lanes that were active in them (lane / (64 * wave) = SIMD utilisation)
     unsigned long long node_wave, node_lane, leaf_wave, leaf_lane, shade_wave, shade_lane;
+    // s_memtime cycles spent inside each block, summed over waves (counting build only)
+    unsigned long long node_cycles, leaf_cycles, shade_cycles, finish_cycles, refill_cycles, begin_cycles;
 };
 
 // kernel arguments (passed by value)
@@ -111,6 +113,8 @@ struct RtLaunch {
     const RtMaterial *materials;
     const RtTexture *textures;
     const uint8_t *image_blob;
+    int32_t n_nodes;
+    int32_t stack_entries; // LDS stack entries per lane for this scene (tree depth + 1, <= RT_STACK_DEPTH)
     uint32_t root;      // 16-bit reference of the BVH root, or RT_CUR_DONE when every prim is hoisted
     int32_t n_hoisted;  // prims [0, n_hoisted) are tested directly for every segment
     int32_t n_prims;

@@ -33,6 +33,7 @@ void run(const RtLaunch &L, int x0, int y0, int x1, int y1, double *out, double 
             for (int s = 0; s < L.spp; ++s) {
                 rtl::PathState ps;
                 rtl::Trav tv;
+                rtl::V3 rad = rtl::mk(0, 0, 0);
                 rtl::start_sample<LENS>(L, (uint32_t)x, (uint32_t)y, (uint32_t)s, &ps);
                 for (;;) {
                     cnt[1]++;
@@ -40,20 +41,20 @@ void run(const RtLaunch &L, int x0, int y0, int x1, int y1, double *out, double 
                     while (tv.cur != RT_CUR_DONE) {
                         if (tv.cur < RT_REF_LEAF) {
                             cnt[2]++;
-                            rtl::trav_node_step(L, tv, st);
+                            rtl::trav_node_step(L.nodes, tv, st);
                         } else {
                             rtl::leaf_step<G, M, T>(L, &ps, tv, st, &cnt[3]);
                         }
                     }
-                    if (rtl::finish_segment<G, M, T>(L, &ps, tv)) break;
+                    if (rtl::finish_segment<G, M, T>(L, &ps, tv, &rad)) break;
                 }
                 cnt[0]++;
                 cnt[4] += ps.g.draws;
-                acc = acc + ps.Lsum;
+                acc = acc + rad;
                 if (samples_out && x == sx && y == sy) {
-                    samples_out[s * 3 + 0] = ps.Lsum.x;
-                    samples_out[s * 3 + 1] = ps.Lsum.y;
-                    samples_out[s * 3 + 2] = ps.Lsum.z;
+                    samples_out[s * 3 + 0] = rad.x;
+                    samples_out[s * 3 + 1] = rad.y;
+                    samples_out[s * 3 + 2] = rad.z;
                 }
             }
             double *o = out + ((size_t)y * L.width + x) * 3;
