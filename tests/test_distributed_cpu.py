@@ -1,0 +1,57 @@
+"""world_size-2 (and 3) gloo test of the multi-rank path of bench.py: every rank owns the
+tiles with tile_id % N == rank, packs them as the kernels do, ONE gather brings equal-sized
+shards to rank 0, which un-permutes them.  The renderer stand-in on CPU is the host compile
+of the lane program (tests only); the permutation logic is what is under test here."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _worker(rank, world, port, W, H, q):
+    sys.path.insert(0, str(ROOT / "tests"))
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib
+
+    import lane_emul_binding as le
+    import sharding_mirror as sm
+    from __graft_entry__ import load_package
+    rt = load_package()
+    scenes = importlib.import_module("ray_tracer_amd.scenes")
+    sc, cam = scenes.build_product(scenes.book_one(1, W / H), device=-1)
+    counts = [rt.shard_tile_count(W, H, r, world) for r in range(world)]
+    pad = max(counts)
+    assert counts[rank] == len(sm.owned_tiles(W, H, rank, world))
+    full, *_ = le.render(sc, cam, W, H, 2, 20, 5)  # sample streams are global: any rank computes the same pixels
+    mine = torch.from_numpy(sm.pack_tiles(full, rank, world, pad).reshape(-1))
+    glist = [torch.zeros_like(mine) for _ in range(world)] if rank == 0 else None
+    dist.gather(mine, glist, dst=0)
+    if rank == 0:
+        img = sm.unpack_tiles(torch.cat(glist).numpy(), pad, world, W, H)
+        q.put(bool(np.array_equal(img, full)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,H", [(2, 40, 24), (3, 35, 19)])
+def test_tile_sharding_gather_unpack(world, W, H, rt, lane_emul):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True

@@ -1,0 +1,221 @@
+"""CPU-side tests of the product's host logic: the C ABI surface, error behaviour,
+Mat4 / camera / tone-map restatements, the flattener and the BVH.  No GPU needed."""
+import ctypes as C
+import math
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_abi_exports_every_declared_symbol(rt):
+    hdr = (ROOT / "include" / "rt_mi355x.h").read_text()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 35
+    lib = C.CDLL(str(rt.LIB_PATH))
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/rt_mi355x.h but not exported"
+    assert declared == set(rt.ABI), "python binding table and header disagree"
+
+
+def test_no_cpu_rendering_path(rt, scenes):
+    """Without a HIP device the product must fail loudly, never fall back."""
+    sc, cam = scenes.build_product(scenes.book_one(1, 1.5), device=-1)
+    with pytest.raises(rt.RtError) as e:
+        sc.render(cam, 16, 16, 1, 5)
+    assert e.value.code == -3 and "no CPU rendering path" in str(e.value)
+    if rt.device_count() == 0:
+        s2 = rt.Scene()
+        s2.sprite(s2.sphere(1.0), s2.lambertian(s2.solid((1, 1, 1))))
+        with pytest.raises(rt.RtError) as e:
+            s2.commit(0)
+        assert e.value.code == -3
+
+
+def test_error_conventions(rt):
+    s = rt.Scene()
+    with pytest.raises(rt.RtError) as e:
+        s.commit(-1)  # BoundingVolumeHierarchyNode::new(vec![]) -> None
+    assert e.value.code == -2
+    with pytest.raises(rt.RtError):
+        s.lambertian(3)  # unknown texture
+    with pytest.raises(rt.RtError):
+        s.sprite(5, None)  # unknown geometry
+    r = s.rectangle(1, 1)
+    with pytest.raises(rt.RtError) as e:
+        s.constant_medium(r, 0.1)
+    assert e.value.code == -4
+    g = s.sphere(1.0)
+    s.sprite(g, None)
+    s.commit(-1)
+    with pytest.raises(rt.RtError) as e:
+        s.sphere(2.0)  # immutable after commit
+    assert e.value.code == -5
+    assert rt.lib().rt_device_count() >= 0
+
+
+def test_mat4_matches_oracle_and_python_mirror(rt, oracle, scenes):
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        t = rng.uniform(-10, 10, 3)
+        ang = rng.uniform(-4, 4)
+        ax = [(1.0, 0, 0), (0, 1.0, 0), (0, 0, 1.0), tuple(rng.uniform(-1, 1, 3))][rng.integers(4)]
+        T, R = rt.Mat4.translation(t), rt.Mat4.rotation(ang, ax)
+        M = T.multiplied(R)
+        To, Ro, Mo = np.zeros(16), np.zeros(16), np.zeros(16)
+        oracle.LIB.orc_kat_mat4_translation(oracle.dp(np.array(t)), oracle.dp(To))
+        oracle.LIB.orc_kat_mat4_rotation(ang, oracle.dp(np.array(ax, dtype=np.float64)), oracle.dp(Ro))
+        oracle.LIB.orc_kat_mat4_multiplied(oracle.dp(To), oracle.dp(Ro), oracle.dp(Mo))
+        assert np.array_equal(T.a, To) and np.array_equal(R.a, Ro) and np.array_equal(M.a, Mo)
+        assert np.array_equal(M.a, scenes.mat4_multiplied(scenes.mat4_translation(t), scenes.mat4_rotation(ang, ax)))
+        inv, invo = M.inversed(), np.zeros(16)
+        assert oracle.LIB.orc_kat_mat4_inversed(oracle.dp(Mo), oracle.dp(invo)) == 1
+        assert np.array_equal(inv.a, invo)
+        assert M.determinant() == oracle.LIB.orc_kat_mat4_determinant(oracle.dp(Mo))
+    assert rt.Mat4(np.zeros(16)).inversed() is None
+    assert np.array_equal(rt.Mat4.identity().a, np.eye(4).reshape(16))
+
+
+def test_camera_matches_oracle(rt, oracle, scenes):
+    for desc in (scenes.book_one(1, 1.5), scenes.cornell(1.0), scenes.cover(1, 1.0)):
+        cam = rt.Camera(*desc.camera)
+        f = np.zeros(9)
+        oracle.LIB.orc_kat_camera_frame(oracle.build_oracle(desc).h, oracle.dp(f))
+        assert np.array_equal(np.array(cam.c.lower_left), f[0:3])
+        assert np.array_equal(np.array(cam.c.horizontal), f[3:6])
+        assert np.array_equal(np.array(cam.c.vertical), f[6:9])
+
+
+def test_tonemap_and_ppm_match_oracle(rt, oracle, tmp_path):
+    rng = np.random.default_rng(1)
+    img = rng.uniform(-0.2, 1.5, (7, 5, 3))
+    img[0, 0] = [float("nan"), -0.0, float("inf")]
+    img[1, 1] = [0.25, 1.0, 4.0]
+    mine = rt.tonemap_rgb8(img)
+    ref = np.zeros_like(mine)
+    oracle.LIB.orc_tonemap_rgb8(oracle.dp(img), 35, ref.ctypes.data_as(C.POINTER(C.c_uint8)))
+    assert np.array_equal(mine, ref)
+    assert mine[1, 1].tolist() == [127, 255, 255] and mine[0, 0].tolist() == [255, 0, 255]
+    a, b = tmp_path / "a.ppm", tmp_path / "b.ppm"
+    rt.write_ppm_p3(a, img)
+    assert oracle.LIB.orc_write_ppm_p3(str(b).encode(), oracle.dp(img), 5, 7) == 0
+    assert a.read_bytes() == b.read_bytes()
+    assert a.read_text().startswith("P3\n5 7\n255\n")
+
+
+def _check_bvh(sc):
+    info = sc.info()
+    nodes = sc.nodes()
+    n_prims, n_h = info["n_prims"], info["n_hoisted"]
+    seen = []
+
+    def walk(ref, box, depth):
+        assert depth <= 24
+        if ref < 0:
+            p = ~ref
+            seen.append(p)
+            b = sc.prim_bounds(p)
+            assert np.all(b[:3] >= box[:3]) and np.all(b[3:] <= box[3:])
+            return depth
+        nd = nodes[ref]
+        deepest = 0
+        for c in range(2):
+            cb = nd[c * 6:c * 6 + 6]
+            assert np.all(cb[:3] >= box[:3]) and np.all(cb[3:] <= box[3:]), "child box escapes its parent"
+            cull = nd[14 + c * 6:14 + c * 6 + 6]
+            assert np.all(cull[:3] < cb[:3]) and np.all(cull[3:] > cb[3:]), "binary32 culling box must strictly contain the binary64 box"
+            # padded by about 2^-21 of the coordinate scale, not more than 2^-19
+            scale = np.maximum(np.maximum(np.abs(cb[:3]), np.abs(cb[3:])), cb[3:] - cb[:3])
+            assert np.all(cb[:3] - cull[:3] <= scale * 2.0 ** -19 + 1e-29)
+            deepest = max(deepest, walk(int(nd[12 + c]), cb, depth + 1))
+        return deepest
+    if n_prims > n_h:
+        big = np.array([-np.inf] * 3 + [np.inf] * 3)
+        root = 0 if len(nodes) else ~n_h
+        d = walk(root, big, 0)
+        assert d == info["max_depth"]
+    assert sorted(seen) == list(range(n_h, n_prims)), "every non-hoisted prim must be a leaf exactly once"
+    return info
+
+
+def test_flatten_book_one(rt, scenes):
+    desc = scenes.book_one(1, 1.5)
+    sc, _ = scenes.build_product(desc, device=-1)
+    info = _check_bvh(sc)
+    assert info["n_prims"] == len(desc.sprites) == 486
+    assert info["n_hoisted"] == 2           # sky (r = 2000) and ground (r = 1000)
+    assert info["feature_mask"] == rt.RT_FEAT_SPHERE_T  # every transform is a pure translation
+    assert info["n_xforms"] == 0 and info["n_nodes"] == info["n_prims"] - info["n_hoisted"] - 1
+    assert info["node_bytes"] == 64 and info["prim_bytes"] == 32
+    # hoisted prims keep creation order: ground (sprite 0) then sky (sprite 1)
+    assert np.allclose(sc.prim_bounds(0), [-1000, -2000, -1000, 1000, 0, 1000], rtol=1e-9)
+    assert np.allclose(sc.prim_bounds(1), [-2000] * 3 + [2000] * 3, rtol=1e-9)
+
+
+def test_flatten_cornell_and_cover(rt, scenes):
+    sc, _ = scenes.build_product(scenes.cornell(), device=-1)
+    info = _check_bvh(sc)
+    assert info["n_prims"] == 8 and info["n_child_prims"] == 12  # two cubes x six faces
+    assert info["feature_mask"] & rt.RT_FEAT_GENERAL
+    d = scenes.cover(1)
+    sc, _ = scenes.build_product(d, device=-1)
+    info = _check_bvh(sc)
+    assert info["n_prims"] == 400 + 1 + 4 + 1 + 1 + 1 + 1000 and info["n_child_prims"] == 2400
+    assert info["feature_mask"] & rt.RT_FEAT_MEDIUM and info["feature_mask"] & rt.RT_FEAT_TEXTURED
+    assert 1 <= info["n_hoisted"] <= 4  # the r = 5000 fog at least
+
+
+def test_flatten_edge_cases(rt, scenes):
+    # single sprite: no BVH nodes at all
+    s = rt.Scene()
+    s.sprite(s.sphere(1.0), s.lambertian(s.solid((1, 1, 1))), scenes.mat4_translation((0, 0, 3)))
+    assert s.commit(-1).info()["n_nodes"] == 0
+    # geometry None and singular transforms are unhittable and dropped; material None is kept
+    s = rt.Scene()
+    g = s.sphere(1.0)
+    s.sprite(None, None)
+    s.sprite(g, None, [0.0] * 16)
+    for i in range(5):
+        s.sprite(g, None, scenes.mat4_translation((10.0 * i, 0, 0)))
+    info = _check_bvh(s.commit(-1))
+    assert info["n_prims"] == 5
+    # five equal, well separated spheres: nothing is scene-spanning, nothing hoisted
+    assert info["n_hoisted"] == 0 and info["n_nodes"] == 4
+    # rotated sphere sprite takes the general-matrix path
+    s = rt.Scene()
+    s.sprite(s.sphere(1.0), None, scenes.mat4_rotation(0.3, (0.0, 1.0, 0.0)))
+    assert s.commit(-1).info()["feature_mask"] & rt.RT_FEAT_GENERAL
+
+
+def test_deep_tree_is_bounded(rt, scenes):
+    """A pathological scene for SAH (nested shells) must still respect the stack bound."""
+    s = rt.Scene()
+    for i in range(200):
+        s.sprite(s.sphere(1.5 ** (i * 0.25)), None, None)
+    info = _check_bvh(s.commit(-1))
+    assert info["max_depth"] <= 24
+
+
+def test_shard_tile_counts(rt):
+    for (w, h) in [(1200, 800), (100, 60), (7, 9), (8, 8)]:
+        total = ((w + 7) // 8) * ((h + 7) // 8)
+        for n in (1, 2, 3, 8):
+            counts = [rt.shard_tile_count(w, h, r, n) for r in range(n)]
+            assert sum(counts) == total and max(counts) - min(counts) <= 1
+    with pytest.raises(rt.RtError):
+        rt.shard_tile_count(10, 10, 2, 2)
+
+
+def test_scene_generators_are_seeded(scenes):
+    a, b, c = scenes.book_one(1), scenes.book_one(1), scenes.book_one(2)
+    assert a.sprites == b.sprites and a.sprites != c.sprites
+    assert 480 <= len(a.sprites) <= 489
+    kinds = [m[0] for m in a.materials]
+    assert 0.2 < kinds.count("lambertian") / len(kinds) < 0.4 and 0.3 < kinds.count("dielectric") / len(kinds) < 0.5
+    cv = scenes.cover(1)
+    heights = [cv.geometries[s[0]][2] for s in cv.sprites[:400]]
+    assert all(1.0 <= hgt < 101.0 for hgt in heights)

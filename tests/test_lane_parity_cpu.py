@@ -1,0 +1,96 @@
+"""The device lane program (ray-tracer_amd/csrc/rt_lane.h) compiled for the HOST and run
+lane by lane over the committed flat scene, against the oracle.  This checks the
+flattener, the SAH BVH with binary32 culling, the hoisting and every per-lane formula on
+machines without a GPU; it claims nothing about the GPU itself (see test_gpu_parity.py).
+Both sides use the host libm here, so agreement must be exact, pixel for pixel."""
+import numpy as np
+import pytest
+
+
+def both(scenes, oracle, lane_emul, desc, W, H, spp, depth, seed=1, **okw):
+    sc, cam = scenes.build_product(desc, device=-1)
+    img, cnt, high = lane_emul.render(sc, cam, W, H, spp, depth, seed)
+    ref, ocnt = oracle.build_oracle(desc, **okw).render(W, H, spp, depth, seed, iterative=True, nthreads=8, counters=True)
+    return img, ref, cnt, ocnt, high, sc
+
+
+@pytest.mark.parametrize("W,H,spp,depth", [(60, 40, 4, 50), (33, 17, 3, 100), (8, 8, 1, 1), (5, 3, 2, 7)])
+def test_book_one_exact(scenes, oracle, lane_emul, W, H, spp, depth):
+    img, ref, cnt, ocnt, high, sc = both(scenes, oracle, lane_emul, scenes.book_one(1, W / H), W, H, spp, depth)
+    assert np.array_equal(img, ref)
+    assert cnt["segments"] == ocnt["segments"] and cnt["rng_draws"] == ocnt["rng_draws"]
+    assert high <= sc.info()["max_depth"] + 1 <= 24
+    # pruning + SAH: far fewer box tests than the reference's unpruned walk
+    assert cnt["nodes_visited"] < ocnt["aabb_tests"]
+
+
+def test_book_one_other_seeds_exact(scenes, oracle, lane_emul):
+    for scene_seed, seed in [(2, 5), (7, 123456789)]:
+        img, ref, *_ = both(scenes, oracle, lane_emul, scenes.book_one(scene_seed, 1.5), 48, 32, 2, 50, seed)
+        assert np.array_equal(img, ref)
+
+
+def test_cornell_exact(scenes, oracle, lane_emul):
+    """Rectangles, rotated sprites, instanced cubes (two transform levels), area light."""
+    img, ref, cnt, ocnt, *_ = both(scenes, oracle, lane_emul, scenes.cornell(1.0), 40, 40, 8, 100)
+    assert np.array_equal(img, ref)
+    assert cnt["segments"] == ocnt["segments"]
+    assert img.max() > 1.0 and img.min() == 0.0  # light visible, black outside the box front
+
+
+def test_cover_exact(scenes, oracle, lane_emul):
+    """ConstantMedium x2 (keyed draws), Isotropic, image texture, 400 instanced cubes, 1000 spheres."""
+    img, ref, cnt, ocnt, *_ = both(scenes, oracle, lane_emul, scenes.cover(1, 1.0), 40, 40, 4, 100)
+    assert np.array_equal(img, ref)
+    assert cnt["segments"] == ocnt["segments"]
+    # keyed medium draws are only evaluated for media the pruned walk still reaches; a skipped
+    # one could not have produced the nearest hit, so the count may drop but never a result
+    assert cnt["rng_draws"] <= ocnt["rng_draws"]
+
+
+def test_textured_and_rotated_primitives_exact(scenes, oracle, lane_emul):
+    d = scenes.SceneDesc()
+    black, white = d.tex_solid((0.05, 0.05, 0.05)), d.tex_solid((0.9, 0.9, 0.9))
+    d.textures.append(("checker", black, white))
+    checker = len(d.textures) - 1
+    img8 = (np.arange(16 * 8 * 3) % 251).astype(np.uint8).reshape(8, 16, 3)
+    d.textures.append(("image", img8))
+    image = len(d.textures) - 1
+    rot = scenes.mat4_multiplied(scenes.mat4_translation((0.0, 0.0, 6.0)), scenes.mat4_rotation(0.7, (0.0, 1.0, 0.0)))
+    d.sprite(d.geom("sphere", 1.5), d.mat("lambertian", checker), rot)                       # general-matrix sphere
+    d.sprite(d.geom("sphere", 1.0), d.mat("lambertian", image), scenes.mat4_translation((3.0, 0.0, 6.0)))
+    d.sprite(d.geom("rectangle", 20.0, 20.0), d.mat("metal", checker, 0.3),
+             scenes.mat4_multiplied(scenes.mat4_translation((0.0, -2.0, 6.0)), scenes.mat4_rotation(scenes.radians(-90.0), (1.0, 0.0, 0.0))))
+    d.sprite(d.geom("cube", 1.0, 2.0, 1.0), d.mat("dielectric", 1.5),
+             scenes.mat4_multiplied(scenes.mat4_translation((-3.0, 0.0, 5.0)), scenes.mat4_rotation(0.4, (0.0, 1.0, 0.0))))
+    d.sprite(d.geom("medium", d.geom("sphere", 1.0), 0.8), d.mat("isotropic", d.tex_solid((0.2, 0.4, 0.9))),
+             scenes.mat4_multiplied(scenes.mat4_translation((0.0, 2.5, 6.0)), scenes.mat4_rotation(1.0, (0.0, 0.0, 1.0))))
+    d.sprite(d.geom("sphere", 60.0), d.mat("diffuse_light", d.tex_solid((1.0, 1.0, 1.0))), None)
+    d.sprite(d.geom("sphere", 0.5), None, scenes.mat4_translation((1.0, 1.5, 4.0)))         # material None -> black
+    d.camera = ((0.0, 0.5, -4.0), (0.0, 0.0, 6.0), (0.0, 1.0, 0.0), 0.9, 1.25, 10.0, 0.02)
+    img, ref, *_ = both(scenes, oracle, lane_emul, d, 50, 40, 6, 60)
+    assert np.array_equal(img, ref)
+
+
+def test_oracle_tree_and_world_form_do_not_matter(scenes, oracle, lane_emul):
+    d = scenes.cornell(1.0)
+    sc, cam = scenes.build_product(d, device=-1)
+    img, *_ = lane_emul.render(sc, cam, 24, 24, 4, 50, 3)
+    for kw in ({"bvh_seed": 1}, {"bvh_seed": 1234}, {"world": "list"}):
+        assert np.array_equal(img, oracle.build_oracle(d, **kw).render(24, 24, 4, 50, 3, iterative=True))
+
+
+def test_per_sample_radiance_exact(scenes, oracle, lane_emul):
+    d = scenes.book_one(1, 1.5)
+    sc, cam = scenes.build_product(d, device=-1)
+    W, H, spp, depth = 60, 40, 32, 50
+    for (x, y) in [(30, 14), (10, 30), (45, 8)]:
+        _, _, _, samples = lane_emul.render(sc, cam, W, H, spp, depth, 9, region=(x, y, x + 1, y + 1), sample_pixel=(x, y))
+        ref = oracle.build_oracle(d).pixel_samples(W, H, spp, depth, 9, x, y, iterative=True)
+        assert np.array_equal(samples, ref)
+
+
+def test_max_depth_zero_is_black(scenes, lane_emul):
+    sc, cam = scenes.build_product(scenes.book_one(1, 1.5), device=-1)
+    img, *_ = lane_emul.render(sc, cam, 16, 8, 2, 0)
+    assert np.array_equal(img, np.zeros((8, 16, 3)))

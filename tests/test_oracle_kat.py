@@ -1,0 +1,366 @@
+"""Known-answer tests that pin the CPU oracle.
+
+The reference (aiifabbf/ray-tracer) cannot be built here and its own test
+(src/mat4.rs:398-408) asserts nothing, so every expected value below is derived by
+hand from the cited reference formula, independently of the
+oracle's code.
+"""
+import ctypes as C
+import math
+import struct
+
+import numpy as np
+import pytest
+
+INF = float("inf")
+
+
+def v3(*a):
+    return np.array(a, dtype=np.float64)
+
+
+def sphere_hit(ob, r, o, d):
+    out = np.zeros(9)
+    ok = ob.LIB.orc_kat_sphere_hit(r, ob.dp(v3(*o)), ob.dp(v3(*d)), ob.dp(out))
+    return ok, out
+
+
+# ---------------------------------------------------------------- Sphere::hit  src/geometry.rs:43-73
+def test_sphere_front_hit(oracle):
+    ok, r = sphere_hit(oracle, 1.0, (0, 0, -5), (0, 0, 1))
+    assert ok == 1
+    t, p, n, u, v = r[0], r[1:4], r[4:7], r[7], r[8]
+    assert t == 4.0  # roots 4 and 6, nearer one
+    assert np.array_equal(p, [0, 0, -1]) and np.array_equal(n, [0, 0, -1])
+    assert u == 0.5 + math.atan2(0.0, -1.0) / (2 * math.pi) == 1.0  # src/geometry.rs:36
+    assert v == 0.5
+
+
+def test_sphere_from_inside_takes_far_root(oracle):
+    ok, r = sphere_hit(oracle, 2.0, (0, 0, 0), (0, 0, 1))
+    assert ok == 1 and r[0] == 2.0  # t1 = -2 fails `> 1e-6`, t2 = 2
+    assert np.array_equal(r[4:7], [0, 0, 1])  # normal always outward (Q4)
+    assert (r[7], r[8]) == (0.5, 0.5)
+
+
+def test_sphere_miss_and_epsilon(oracle):
+    assert sphere_hit(oracle, 1.0, (2, 0, -5), (0, 0, 1))[0] == 0  # discriminant < 0
+    assert sphere_hit(oracle, 1.0, (0, 0, 5), (0, 0, 1))[0] == 0  # both roots negative
+    # origin 1e-7 in front of the surface point: t1 ~ -(2 - 1e-7), t2 = 1e-7 < 1e-6 -> miss (Q3)
+    assert sphere_hit(oracle, 1.0, (0, 0, 1 - 1e-7), (0, 0, 1))[0] == 0
+    ok, r = sphere_hit(oracle, 1.0, (0, 0, 1 - 1e-5), (0, 0, 1))
+    assert ok == 1 and abs(r[0] - 1e-5) < 1e-15
+
+
+def test_sphere_unnormalised_direction(oracle):
+    # a = 4, b = -20, c = 24 -> disc = 16, roots (20 -/+ 4)/8 = 2, 3
+    ok, r = sphere_hit(oracle, 1.0, (0, 0, -5), (0, 0, 2))
+    assert ok == 1 and r[0] == 2.0 and np.array_equal(r[1:4], [0, 0, -1])
+
+
+def test_sphere_nan_direction_misses(oracle):
+    assert sphere_hit(oracle, 1.0, (0, 0, -5), (float("nan"), 0, 1))[0] == 0  # Q8 paths die
+
+
+# ---------------------------------------------------------------- Rectangle::hit  src/geometry.rs:153-180
+def test_rectangle_hit(oracle):
+    out = np.zeros(9)
+    ok = oracle.LIB.orc_kat_rectangle_hit(2.0, 4.0, oracle.dp(v3(0.5, 1, 3)), oracle.dp(v3(0, 0, -1)), oracle.dp(out))
+    assert ok == 1
+    assert out[0] == 3.0 and np.array_equal(out[1:4], [0.5, 1, 0])
+    assert np.array_equal(out[4:7], [0, 0, 1])  # one-sided normal, two-sided hit (Q4)
+    assert (out[7], out[8]) == (0.75, 0.75)
+    # from behind: still hit, same normal
+    ok = oracle.LIB.orc_kat_rectangle_hit(2.0, 4.0, oracle.dp(v3(0.5, 1, -3)), oracle.dp(v3(0, 0, 1)), oracle.dp(out))
+    assert ok == 1 and np.array_equal(out[4:7], [0, 0, 1])
+
+
+def test_rectangle_rejects(oracle):
+    out = np.zeros(9)
+    f = oracle.LIB.orc_kat_rectangle_hit
+    assert f(2.0, 4.0, oracle.dp(v3(1.5, 0, 3)), oracle.dp(v3(0, 0, -1)), oracle.dp(out)) == 0  # x outside
+    assert f(2.0, 4.0, oracle.dp(v3(0, 0, 3)), oracle.dp(v3(1, 0, 0)), oracle.dp(out)) == 0    # parallel: t = inf
+    assert f(2.0, 4.0, oracle.dp(v3(0, 0, 0)), oracle.dp(v3(1, 0, 0)), oracle.dp(out)) == 0    # 0/0 = NaN
+    assert f(2.0, 4.0, oracle.dp(v3(0, 0, 1e-7)), oracle.dp(v3(0, 0, -1)), oracle.dp(out)) == 0  # t < 1e-6
+    assert f(2.0, 4.0, oracle.dp(v3(1.0, 2.0, 1)), oracle.dp(v3(0, 0, -1)), oracle.dp(out)) == 1  # bounds inclusive
+
+
+# ---------------------------------------------------------------- AABB::hit  src/optimize.rs:61-82
+@pytest.mark.parametrize("o,d,expect", [
+    ((0, 0, -5), (0, 0, 1), 1),
+    ((2, 0, -5), (0, 0, 1), 0),
+    ((1, 0, -5), (0, 0, 1), 1),      # on the face: (1-1)*inf = NaN falls through the selects
+    ((0, 0, 5), (0, 0, 1), 0),       # behind: tmax = -4 <= tmin = 0
+    ((0, 0, 0), (0, 0, 1), 1),       # origin inside
+    ((0, 0, -5), (0, 0, -1), 0),     # pointing away
+    ((0, 0, -5), (-0.0, 0, 1), 1),   # d = -0.0 -> inv = -inf -> swap, still a hit
+])
+def test_aabb(oracle, o, d, expect):
+    mn, mx = v3(-1, -1, -1), v3(1, 1, 1)
+    assert oracle.LIB.orc_kat_aabb_hit(oracle.dp(mn), oracle.dp(mx), oracle.dp(v3(*o)), oracle.dp(v3(*d))) == expect
+
+
+# ---------------------------------------------------------------- Vec3  src/vec3.rs:100-124
+def test_reflect_refract(oracle):
+    s = 1 / math.sqrt(2)
+    out = np.zeros(3)
+    oracle.LIB.orc_kat_reflect(oracle.dp(v3(s, -s, 0)), oracle.dp(v3(0, 1, 0)), oracle.dp(out))
+    assert np.allclose(out, [s, s, 0], rtol=0, atol=1e-16)
+    assert oracle.LIB.orc_kat_refract(oracle.dp(v3(0, -1, 0)), oracle.dp(v3(0, 1, 0)), 1 / 1.5, oracle.dp(out)) == 1
+    assert np.array_equal(out, [0, -1, 0])  # eta*(d - n*dt) - n*sqrt(k) with dt = -1, k = 1
+    # total internal reflection: eta = 1.5, grazing
+    g = v3(math.sin(1.2), -math.cos(1.2), 0)
+    assert oracle.LIB.orc_kat_refract(oracle.dp(g), oracle.dp(v3(0, 1, 0)), 1.5, oracle.dp(out)) == 0
+    # the result is built from the UN-normalised vector (src/vec3.rs:119-121)
+    assert oracle.LIB.orc_kat_refract(oracle.dp(v3(0, -2, 0)), oracle.dp(v3(0, 1, 0)), 0.5, oracle.dp(out)) == 1
+    assert np.array_equal(out, [0, 0.5 * (-2 + 1) - 1.0, 0])  # 0.5*(d - n*dt) - n*sqrt(1), dt = -1
+
+
+def test_schlick(oracle):  # src/material.rs:140-143
+    assert abs(oracle.LIB.orc_kat_schlick(0.0, 1 / 1.5, 1.0) - 0.04) < 1e-16
+    r0 = ((1.5 - 1) / (1.5 + 1)) ** 2
+    assert abs(oracle.LIB.orc_kat_schlick(math.pi / 2, 1.5, 1.0) - (r0 + (1 - r0) * (1 - math.cos(math.pi / 2)) ** 5)) < 1e-15
+
+
+# ---------------------------------------------------------------- Mat4 / Vec4  src/mat4.rs, src/vec4.rs:78-91
+def test_mat4(oracle):
+    T = np.zeros(16)
+    oracle.LIB.orc_kat_mat4_translation(oracle.dp(v3(1, 2, 3)), oracle.dp(T))
+    assert np.array_equal(T, [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 1, 2, 3, 1])  # column-major, m[12..14]
+    inv = np.zeros(16)
+    assert oracle.LIB.orc_kat_mat4_inversed(oracle.dp(T), oracle.dp(inv)) == 1
+    assert np.array_equal(inv, [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, -1, -2, -3, 1])
+    assert oracle.LIB.orc_kat_mat4_determinant(oracle.dp(T)) == 1.0
+    R = np.zeros(16)
+    oracle.LIB.orc_kat_mat4_rotation(math.pi / 2, oracle.dp(v3(0, 1, 0)), oracle.dp(R))
+    out = np.zeros(4)
+    oracle.LIB.orc_kat_vec4_transformed(oracle.dp(np.array([1.0, 0, 0, 0])), oracle.dp(R), oracle.dp(out))
+    assert np.allclose(out, [0, 0, -1, 0], atol=1e-16)  # first column = (c, 0, -s, 0)
+    # self * other: translation then rotation applied to a point = rotate first, then translate
+    M = np.zeros(16)
+    oracle.LIB.orc_kat_mat4_multiplied(oracle.dp(T), oracle.dp(R), oracle.dp(M))
+    oracle.LIB.orc_kat_vec4_transformed(oracle.dp(np.array([1.0, 0, 0, 1])), oracle.dp(M), oracle.dp(out))
+    assert np.allclose(out, [1, 2, 2, 1], atol=1e-15)
+    # singular
+    assert oracle.LIB.orc_kat_mat4_inversed(oracle.dp(np.zeros(16)), oracle.dp(inv)) == 0
+
+
+# ---------------------------------------------------------------- camera  src/camera.rs:25-59,91-106
+def test_camera_frame_book_one(oracle, scenes):
+    o = oracle.build_oracle(scenes.book_one(1, 1.5))
+    f = np.zeros(9)
+    oracle.LIB.orc_kat_camera_frame(o.h, oracle.dp(f))
+    ll, hor, ver = f[0:3], f[3:6], f[6:9]
+    w = v3(13, 2, 3) / math.sqrt(182)
+    u = v3(w[2], 0, -w[0])           # up x w with up = ey, NOT normalised (Q1)
+    assert abs(np.linalg.norm(u) - 0.98895) < 1e-5
+    height = math.tan(math.radians(20) / 2) * 2
+    assert np.allclose(hor, u * (1.5 * height) * 10, rtol=1e-15)
+    vv = np.cross(w, u)
+    assert np.allclose(ver, vv * height * 10, rtol=1e-14, atol=1e-16)
+    assert np.allclose(ll, v3(13, 2, 3) - hor / 2 - ver / 2 - w * 10, rtol=1e-14)
+
+
+def test_camera_ray_pinhole_and_lens(oracle, scenes):
+    d = scenes.cornell(1.0)
+    o = oracle.build_oracle(d)
+    r = np.zeros(6)
+    oracle.LIB.orc_kat_camera_ray(o.h, 0.5, 0.5, 1, 0, oracle.dp(r))
+    assert np.array_equal(r[0:3], [277.5, 277.5, -800]) and np.allclose(r[3:6], [0, 0, 1], atol=1e-15)
+    # lens: offset is the SCALAR rd.x*u + rd.y*v added to all three components of eye (Q2)
+    ob = oracle.build_oracle(scenes.book_one(1, 1.5))
+    disk = np.zeros(3)
+    oracle.LIB.orc_kat_random_in_unit_disk(5, 9, oracle.dp(disk))
+    oracle.LIB.orc_kat_camera_ray(ob.h, 0.25, 0.75, 5, 9, oracle.dp(r))
+    off = (disk[0] * 0.05) * 0.25 + (disk[1] * 0.05) * 0.75
+    assert np.array_equal(r[0:3], v3(13, 2, 3) + off)
+    assert abs(np.linalg.norm(r[3:6]) - 1) < 1e-15
+
+
+# ---------------------------------------------------------------- BVH build  src/optimize.rs:366-440
+def test_bvh_node_counts(oracle, scenes):
+    # nodes(n) = 1 for n <= 2, else 1 + nodes(floor(n/2)) + nodes(ceil(n/2))
+    def nodes(n):
+        return 1 if n <= 2 else 1 + nodes(n // 2) + nodes(n - n // 2)
+    d = scenes.book_one(1, 1.5)
+    o = oracle.build_oracle(d)
+    assert oracle.LIB.orc_kat_world_node_count(o.h) == nodes(len(d.sprites)) == 511
+    assert nodes(6) == 7 and nodes(1000) == 1023
+    c = oracle.build_oracle(scenes.cornell())
+    assert oracle.LIB.orc_kat_world_node_count(c.h) == nodes(8) == 7
+    # empty input: BoundingVolumeHierarchyNode::new(vec![]) is None
+    e = oracle.OracleScene()
+    assert oracle.LIB.orc_world_bvh(e.h, (C.c_int * 1)(), 0, 1) == -1
+
+
+def test_nearest_hit_does_not_depend_on_the_tree(oracle, scenes):
+    """F7: no pruning, no ordering -> any tree (any axis seed) and the plain Vec scan agree."""
+    d = scenes.book_one(3, 1.5)
+    a = oracle.build_oracle(d, bvh_seed=1).render(40, 24, 2, 20, seed=4)
+    b = oracle.build_oracle(d, bvh_seed=99).render(40, 24, 2, 20, seed=4)
+    c = oracle.build_oracle(d, world="list").render(40, 24, 2, 20, seed=4)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+
+
+# ---------------------------------------------------------------- tone map  examples/book-one.rs:90-98
+def test_tonemap(oracle):
+    rgb = np.array([0.25, 1.0, 4.0, float("nan"), -0.0, -1.0, 0.0, 1e-300, INF], dtype=np.float64)
+    out = np.zeros(9, dtype=np.uint8)
+    oracle.LIB.orc_tonemap_rgb8(oracle.dp(rgb), 3, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    # sqrt(0.25)*255 = 127.5 -> 127 (truncation); NaN and negative (sqrt -> NaN) -> 255 via f64::min; -0.0 -> 0
+    assert out.tolist() == [127, 255, 255, 255, 0, 255, 0, 0, 255]
+
+
+def test_ppm_layout(oracle, tmp_path):
+    img = np.zeros((2, 3, 3))
+    img[1, 0] = [1, 0, 0]  # top-left when printed (rows go from y = H-1 down)
+    img[0, 2] = [0, 0, 0.25]
+    p = tmp_path / "a.ppm"
+    assert oracle.LIB.orc_write_ppm_p3(str(p).encode(), oracle.dp(img), 3, 2) == 0
+    lines = p.read_text().split("\n")
+    assert lines[:3] == ["P3", "3 2", "255"]
+    assert lines[3] == "255 0 0" and lines[8] == "0 0 127" and len(lines) == 10 and lines[9] == ""
+
+
+# ---------------------------------------------------------------- RNG contract  include/rt_rng.h
+def test_splitmix64_published_vectors(scenes):
+    """mix64/GAMMA are SplitMix64: first outputs for state 1234567 (Vigna's splitmix64.c)."""
+    x = 1234567
+    outs = []
+    for _ in range(5):
+        x = (x + scenes.GAMMA) & scenes.MASK
+        outs.append(scenes.mix64(x))
+    assert outs == [6457827717110365317, 3203168211198807973, 9817491932198370423, 4593380528125082431, 16408922859458223821]
+
+
+def test_c_rng_equals_python_mirror(oracle, scenes):
+    for seed, stream in [(0, 0), (1, 0), (1, 7), (12345, scenes.SCENE_STREAM), (2**63 + 5, 2**39)]:
+        out = (C.c_uint64 * 16)()
+        oracle.LIB.orc_kat_rng_u64(seed, stream, 16, out)
+        g = scenes.HostRng(seed, stream)
+        assert list(out) == [g.next_u64() for _ in range(16)]
+    # streams never share states: (stream, n) -> base + n*G is injective for n < 2^24
+    assert (scenes.HostRng(1, 1).base - scenes.HostRng(1, 0).base) & scenes.MASK == ((1 << 24) * scenes.GAMMA) & scenes.MASK
+
+
+def test_float_conversions():
+    def v12(x):
+        return struct.unpack("<d", struct.pack("<Q", (x >> 12) | 0x3FF0000000000000))[0]
+    # rand 0.7 Standard: (x >> 11) * 2^-53; gen_range: v12*scale + (low - scale)
+    assert (0 >> 11) * 2.0 ** -53 == 0.0 and ((2**64 - 1) >> 11) * 2.0 ** -53 == 1 - 2.0 ** -53
+    assert v12(0) - 1.0 == 0.0 and v12(2**64 - 1) - 1.0 == 1 - 2.0 ** -52
+    assert v12(0) * 2.0 - 3.0 == -1.0 and v12(2**64 - 1) * 2.0 - 3.0 == 1 - 2.0 ** -51
+
+
+def test_random_in_unit_sphere_and_disk(oracle, scenes):
+    out = np.zeros(3)
+    for seed in range(20):
+        oracle.LIB.orc_kat_random_in_unit_sphere(seed, 3, oracle.dp(out))
+        g = scenes.HostRng(seed, 3)
+        while True:  # src/util.rs:6-15
+            p = [(g.next_u64() >> 11) * 2.0 ** -53 * 2.0 - 1.0 for _ in range(3)]
+            if p[0] * p[0] + p[1] * p[1] + p[2] * p[2] < 1.0:
+                break
+        assert out.tolist() == p
+        oracle.LIB.orc_kat_random_in_unit_disk(seed, 3, oracle.dp(out))
+        assert out[2] == 0.0 and math.sqrt(out[0] ** 2 + out[1] ** 2) < 1.0
+
+
+# ---------------------------------------------------------------- textures  src/material.rs:211-265
+def test_textures(oracle):
+    s = oracle.OracleScene()
+    a = oracle.LIB.orc_tex_solid(s.h, 0.1, 0.2, 0.3)
+    b = oracle.LIB.orc_tex_solid(s.h, 0.9, 0.8, 0.7)
+    ck = oracle.LIB.orc_tex_checker(s.h, a, b)
+    out = np.zeros(3)
+    # sin(20*pi*u)*sin(20*pi*v) > 0 -> black (first) texture, in uv space (Q11)
+    oracle.LIB.orc_kat_texture_value(s.h, ck, 0.025, 0.025, oracle.dp(out))
+    assert out.tolist() == [0.1, 0.2, 0.3]
+    oracle.LIB.orc_kat_texture_value(s.h, ck, 0.025, 0.075, oracle.dp(out))
+    assert out.tolist() == [0.9, 0.8, 0.7]
+    img = np.arange(4 * 2 * 3, dtype=np.uint8).reshape(2, 4, 3)  # h=2, w=4
+    it = oracle.LIB.orc_tex_image_rgb8(s.h, img.ctypes.data_as(C.POINTER(C.c_uint8)), 4, 2)
+    # px = (u*w) as u32, py = ((1-v)*h) as u32  (examples/main.rs:271-274)
+    oracle.LIB.orc_kat_texture_value(s.h, it, 0.6, 0.9, oracle.dp(out))
+    assert out.tolist() == [c / 255.0 for c in img[0, 2]]
+    oracle.LIB.orc_kat_texture_value(s.h, it, 1.0, 0.0, oracle.dp(out))  # u == 1.0 would panic upstream: clamped
+    assert out.tolist() == [c / 255.0 for c in img[1, 3]]
+    oracle.LIB.orc_kat_texture_value(s.h, it, float("nan"), 0.99, oracle.dp(out))  # NaN as u32 = 0
+    assert out.tolist() == [c / 255.0 for c in img[0, 0]]
+
+
+# ---------------------------------------------------------------- Sprite / ConstantMedium
+def test_sprite_transform_and_material(oracle, scenes):
+    d = scenes.SceneDesc()
+    m = d.lambertian_rgb((0.5, 0.5, 0.5))
+    d.sprite(d.geom("sphere", 1.0), m, scenes.mat4_translation((0, 0, 10)))
+    d.sprite(d.geom("sphere", 1.0), None, scenes.mat4_translation((0, 5, 0)))
+    d.camera = ((0, 0, 0), (0, 0, 1), (0, 1, 0), 1.0, 1.0, 1.0, 0.0)
+    o = oracle.build_oracle(d)
+    out = np.zeros(10)
+    assert oracle.LIB.orc_kat_world_hit(o.h, oracle.dp(v3(0, 0, 0)), oracle.dp(v3(0, 0, 1)), 1, 0, oracle.dp(out)) == 1
+    assert out[0] == 9.0 and np.array_equal(out[1:4], [0, 0, 9]) and np.array_equal(out[4:7], [0, 0, -1]) and out[9] == m
+    assert oracle.LIB.orc_kat_world_hit(o.h, oracle.dp(v3(0, 0, 0)), oracle.dp(v3(0, 1, 0)), 1, 0, oracle.dp(out)) == 1
+    assert out[9] == -1  # material None survives into the record; color() then returns black
+
+
+def test_constant_medium_formulas(oracle, scenes):
+    """src/volume.rs:46-100 incl. quirk Q9, with the keyed draw of include/rt_rng.h."""
+    density = 0.7
+    d = scenes.SceneDesc()
+    d.sprite(d.geom("medium", d.geom("sphere", 1.0), density), d.mat("isotropic", d.tex_solid((1, 1, 1))), None)
+    d.camera = ((0, 0, -5), (0, 0, 0), (0, 1, 0), 1.0, 1.0, 1.0, 0.0)
+    o = oracle.build_oracle(d)
+    seed, stream = 11, 22
+    g = scenes.HostRng(seed, stream)
+    n = (1 << 23) + (0 << 10) + 0  # segment 0, medium slot 0
+    x = scenes.mix64((g.base + n * scenes.GAMMA) & scenes.MASK)
+    U = struct.unpack("<d", struct.pack("<Q", (x >> 12) | 0x3FF0000000000000))[0] - 1.0
+    dist = (-1.0 / density) * math.log(U)
+    out = np.zeros(10)
+    hit = oracle.LIB.orc_kat_world_hit(o.h, oracle.dp(v3(0, 0, -5)), oracle.dp(v3(0, 0, 1)), seed, stream, oracle.dp(out))
+    inside = 2.0 - 1e-6  # chord seen by the restarted ray
+    if dist > inside + 1e-9:
+        assert hit == 0
+    else:
+        assert hit == 1
+        assert abs(out[0] - (4.0 + dist)) < 1e-12                       # t = t1 + s
+        assert abs(out[3] - ((-1.0 + 1e-6) + (4.0 + dist))) < 1e-12     # p on the RESTARTED ray: t1 further (Q9)
+        assert np.allclose(out[4:7], [0, 0, 0], atol=1e-15)             # mean of the two boundary normals
+    # origin inside: t = s, p = o + d*s, n = n1
+    hit = oracle.LIB.orc_kat_world_hit(o.h, oracle.dp(v3(0, 0, 0)), oracle.dp(v3(0, 0, 1)), seed, stream, oracle.dp(out))
+    if dist > 1.0:
+        assert hit == 0
+    else:
+        assert hit == 1 and abs(out[0] - dist) < 1e-15 and abs(out[3] - dist) < 1e-15 and np.array_equal(out[4:7], [0, 0, 1])
+
+
+# ---------------------------------------------------------------- render::color  src/render.rs:5-29
+def test_furnace_and_black(oracle, scenes):
+    """All-light enclosure: every pixel is exactly the emission; max_depth 0 and empty view: black (Q12)."""
+    d = scenes.SceneDesc()
+    d.sprite(d.geom("sphere", 100.0), d.mat("diffuse_light", d.tex_solid((0.5, 0.7, 1.0))), None)
+    d.camera = ((0, 0, 0), (0, 0, 1), (0, 1, 0), 1.0, 1.0, 1.0, 0.0)
+    o = oracle.build_oracle(d)
+    img = o.render(8, 8, 4, 10, seed=1)
+    assert np.array_equal(img, np.broadcast_to([0.5, 0.7, 1.0], img.shape))
+    assert np.array_equal(o.render(8, 8, 4, 0, seed=1), np.zeros((8, 8, 3)))
+    # lambertian albedo 0.5 inside a light: 1 bounce max -> first term only survives depth 1
+    d2 = scenes.SceneDesc()
+    d2.sprite(d2.geom("sphere", 1.0), d2.lambertian_rgb((0.5, 0.5, 0.5)), scenes.mat4_translation((0, 0, 5)))
+    d2.sprite(d2.geom("sphere", 100.0), d2.mat("diffuse_light", d2.tex_solid((1, 1, 1))), None)
+    d2.camera = ((0, 0, 0), (0, 0, 5), (0, 1, 0), 0.2, 1.0, 1.0, 0.0)
+    o2 = oracle.build_oracle(d2)
+    centre = o2.render(9, 9, 16, 50, seed=1)[4, 4]
+    assert np.allclose(centre, 0.5, atol=1e-12)  # convex object in a uniform light: exactly albedo
+    assert np.array_equal(o2.render(9, 9, 4, 1, seed=1)[4, 4], [0, 0, 0])  # depth exhausted after the scatter
+
+
+def test_recursive_and_iterative_forms_agree(oracle, scenes):
+    d = scenes.book_one(1, 1.5)
+    o = oracle.build_oracle(d)
+    a = o.render(48, 32, 4, 50, seed=1, iterative=False, nthreads=4)
+    b = o.render(48, 32, 4, 50, seed=1, iterative=True, nthreads=4)
+    assert np.abs(a - b).max() <= 4e-16 * max(1.0, a.max())
+    # threads only deal rows: identical image for any thread count
+    assert np.array_equal(a, o.render(48, 32, 4, 50, seed=1, iterative=False, nthreads=1))
