@@ -148,6 +148,12 @@ def main():
                             + cnt["segments"] * info["material_bytes"]) / ns + 24.0 / spp
         launch_samples = total_samples / world
         achieved = bytes_per_sample * launch_samples / (kernel_avg_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes of this same command,
+        # tools/profile.sh; corrected as MI355X_MICROARCH.md prescribes); only valid for the profiled workload
+        traffic = None
+        tf = ROOT / "profiles" / "pmc_traffic.json"
+        if tf.exists() and (W, H, spp, depth, world) == (1200, 800, 500, 100, 1):
+            traffic = json.load(open(tf))["hbm_bytes_per_launch"]
         res = {
             "metric": "Msamples/sec (pixels x spp), book-one 1200x800x500spp",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -157,7 +163,8 @@ def main():
                        "scene_seed": a.scene_seed, "render_seed": a.seed, "n_spheres": info["n_prims"],
                        "bvh_nodes": info["n_nodes"], "sharding": f"8x8 tiles, tile_id % {world}, one RCCL gather"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "note": "algorithmic bytes are served from LDS/L1/L2 (scene < 100 KB): the kernel is VALU-issue bound, see DESIGN.md",
                          "kernel": "render_kernel", "kernel_ms": kernel_avg_ms, "algorithmic_bytes_per_sample": bytes_per_sample,
                          "segments_per_sample": cnt["segments"] / ns, "nodes_per_sample": cnt["nodes_visited"] / ns,
                          "prims_per_sample": cnt["prims_tested"] / ns,

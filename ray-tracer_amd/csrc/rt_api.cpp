@@ -287,7 +287,7 @@ static unsigned kernel_features(const rt_scene *s) {
 static size_t sample_workspace_cap() {
     const char *e = std::getenv("RT_SAMPLE_WORKSPACE_MB");
     if (e && *e) return (size_t)std::strtoull(e, nullptr, 10) << 20;
-    return (size_t)24 << 30; // 24 GiB of the 288 GB
+    return (size_t)32 << 30; // 32 GiB of the 288 GB
 }
 
 int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_render_params *p, void *d_tiles_out, void *d_counters,
@@ -308,8 +308,8 @@ int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_render_pa
         HIP_TRY(hipMemsetAsync(d_tiles_out, 0, tile_doubles * sizeof(double), st));
         return RT_OK;
     }
-    // pass size: as many samples per pixel as the workspace cap allows
-    const size_t bytes_per_spp = tile_doubles * sizeof(double);
+    // pass size: as many samples per pixel as the workspace cap allows (32-byte record per sample)
+    const size_t bytes_per_spp = (size_t)n_owned * RT_TILE_PIXELS * 4 * sizeof(double);
     int chunk = (int)std::min<size_t>((size_t)p->spp, std::max<size_t>(1, sample_workspace_cap() / bytes_per_spp));
     // slot indices are 32-bit
     chunk = (int)std::min<size_t>((size_t)chunk, (size_t)0xFFFFFFFFu / ((size_t)n_owned * RT_TILE_PIXELS));

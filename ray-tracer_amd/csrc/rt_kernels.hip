@@ -24,8 +24,8 @@
 //
 // reduce_kernel -- pixel = (((s_0 + s_1) + s_2) + ...) / spp in sample order, the
 //   rounding of `pixel += color(...)` in examples/book-one.rs:69-76.  Per-sample
-//   radiance takes 24 B/sample of HBM (11.5 GB for 1200x800x500; the MI355X has
-//   288 GB) and ~2 x 24 B/sample of traffic, noise next to the traversal.
+//   radiance takes one 32-byte record per sample (15.4 GB for 1200x800x500; the
+//   MI355X has 288 GB) written once and read once, noise next to the traversal.
 //
 // No MFMA anywhere: the workload has no dense contraction.
 
@@ -132,10 +132,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void render_kernel(const
                     if (COUNT) ++c_segs;
                     rtl::V3 rad;
                     if (rtl::finish_segment<GENERAL, MEDIUM, TEXTURED>(L, &ps, tv, &rad)) {
-                        double *o = L.samples + (size_t)slot * 3;
-                        o[0] = rad.x;
-                        o[1] = rad.y;
-                        o[2] = rad.z;
+                        // one 32-byte aligned record per sample, two 16-byte stores: whole sectors,
+                        // no read-modify-write of partially written lines at the memory side
+                        double2 *o = reinterpret_cast<double2 *>(L.samples + (size_t)slot * 4);
+                        o[0] = make_double2(rad.x, rad.y);
+                        o[1] = make_double2(rad.z, 0.0);
                         has_path = false;
                         if (COUNT) {
                             c_draws += ps.g.draws;
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void render_kernel(const
 
 // Sum this pass's samples in sample order on top of the running sums; the last
 // pass divides by spp (`pixel /= subPixelSampleCount`, examples/book-one.rs:76).
-// One thread per owned pixel; consecutive threads read consecutive 24-byte records.
+// One thread per owned pixel; consecutive threads read consecutive 32-byte records.
 __global__ void reduce_kernel(const double *samples, double *tiles, int n_owned_tiles, int s_count, int first_pass,
                               int last_pass, int spp, int width, int height, int tiles_x, int shard_index, int shard_count) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -276,12 +277,13 @@ __global__ void reduce_kernel(const double *samples, double *tiles, int n_owned_
         g = out[1];
         b = out[2];
     }
-    const double *p = samples + ((size_t)k * (size_t)s_count * RT_TILE_PIXELS + (size_t)pix) * 3;
+    const double2 *p = reinterpret_cast<const double2 *>(samples + ((size_t)k * (size_t)s_count * RT_TILE_PIXELS + (size_t)pix) * 4);
     for (int s = 0; s < s_count; ++s) {
-        r += p[0];
-        g += p[1];
-        b += p[2];
-        p += RT_TILE_PIXELS * 3;
+        const double2 a = p[0], c = p[1];
+        r += a.x;
+        g += a.y;
+        b += c.x;
+        p += RT_TILE_PIXELS * 2;
     }
     if (last_pass) {
         const double n = (double)spp;

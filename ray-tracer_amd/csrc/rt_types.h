@@ -127,7 +127,7 @@ struct RtLaunch {
     int32_t s0, s_count;
     int32_t jobs_per_tile, n_jobs;
     unsigned int *job_counter; // zeroed before the launch
-    double *samples;           // per-sample radiance of this pass: [owned tile][s - s0][pixel][3]
+    double *samples;           // per-sample radiance of this pass: [owned tile][s - s0][pixel][4] (32-byte records)
     RtCounters *counters;      // may be null
 };
 
