@@ -40,6 +40,10 @@ def parse():
     ap.add_argument("--scene-seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 path on a box with fewer GPUs (shards staged through host memory)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--check", action="store_true", help="rank 0 also renders the whole image alone and compares")
     return ap.parse_args()
 
 
@@ -76,11 +80,16 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {a.gpus} does not match WORLD_SIZE {world}")
+    if a.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     rt = load_package()
     scenes = importlib.import_module("ray_tracer_amd.scenes")
@@ -99,9 +108,15 @@ def main():
     def step():
         stream = torch.cuda.current_stream().cuda_stream
         sc.render_tiles_device(cam, W, H, spp, depth, a.seed, (rank, world), mine.data_ptr(), None, stream)
-        if world > 1:
+        if world > 1 and a.backend == "nccl":
             glist = list(gathered.chunk(world)) if rank == 0 else None
-            dist.gather(mine, glist, dst=0)
+            dist.gather(mine, glist, dst=0)  # the one collective of the path (RCCL over xGMI)
+        elif world > 1:
+            hm = mine.cpu()
+            hl = [torch.zeros_like(hm) for _ in range(world)] if rank == 0 else None
+            dist.gather(hm, hl, dst=0)
+            if rank == 0:
+                gathered.copy_(torch.cat(hl))
         if rank == 0:
             src = gathered if world > 1 else mine
             rt.unpack_tiles_device(src.data_ptr(), pad_tiles, world, W, H, image.data_ptr(), stream)
@@ -174,6 +189,9 @@ def main():
                                                for b in ("node", "leaf", "shade", "finish", "refill", "begin")}},
             "wall_s": dt, "last_kernel_ms": last_kernel_ms,
         }
+        if a.check:
+            whole = sc.render(cam, W, H, spp, depth, a.seed)
+            res["image_matches_single_gpu"] = bool(np.array_equal(host_image.numpy().reshape(H, W, 3), whole))
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(desc, W, H, depth, a.seed, a.cpu_seconds)
         else:
