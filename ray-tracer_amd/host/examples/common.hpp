@@ -1,0 +1,141 @@
+// common.hpp -- shared driver of the three example programs: the reference's `main()`s
+// (examples/book-one.rs:25-101, cornell-box.rs:24-204, main.rs:38-154) have every parameter
+// as a literal; here they are flags with the reference's values as defaults.
+#ifndef RT_EXAMPLES_COMMON_HPP
+#define RT_EXAMPLES_COMMON_HPP
+
+#include "../ray_tracer.hpp"
+#include "../../../include/rt_rng.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <typeinfo>
+#include <vector>
+
+namespace rtx {
+using namespace ray_tracer;
+
+struct Options {
+    int width, height, spp, depth = 100, device = 0;
+    uint64_t seed = 1, scene_seed = 1;
+    std::string out = "-";
+    bool describe = false;
+};
+
+inline Options parse(int argc, char **argv, int w, int h, int spp) {
+    Options o;
+    o.width = w;
+    o.height = h;
+    o.spp = spp;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto next = [&]() -> const char * {
+            if (i + 1 >= argc) {
+                std::fprintf(stderr, "missing value for %s\n", a.c_str());
+                std::exit(2);
+            }
+            return argv[++i];
+        };
+        if (a == "--width") o.width = std::atoi(next());
+        else if (a == "--height") o.height = std::atoi(next());
+        else if (a == "--spp") o.spp = std::atoi(next());
+        else if (a == "--depth") o.depth = std::atoi(next());
+        else if (a == "--device") o.device = std::atoi(next());
+        else if (a == "--seed") o.seed = std::strtoull(next(), nullptr, 10);
+        else if (a == "--scene-seed") o.scene_seed = std::strtoull(next(), nullptr, 10);
+        else if (a == "--out") o.out = next();
+        else if (a == "--describe") o.describe = true;
+        else {
+            std::fprintf(stderr, "usage: %s [--width W] [--height H] [--spp N] [--depth D] [--seed S] [--scene-seed S] "
+                                 "[--device I] [--out file.ppm|-] [--describe]\n", argv[0]);
+            std::exit(2);
+        }
+    }
+    return o;
+}
+
+// host-side generator of include/rt_rng.h in place of thread_rng()
+struct SceneRng {
+    rt_rng g;
+    explicit SceneRng(uint64_t seed) { rt_rng_init(&g, seed, RT_RNG_SCENE_STREAM); }
+    double gen_range(double lo, double hi) { return rt_rng_gen_range(&g, lo, hi); }
+};
+
+// canonical text dump of the sprite list (tests compare it with the Python scene description)
+inline void describe_texture(const Texture *t) {
+    if (auto s = dynamic_cast<const SolidColor *>(t)) std::printf("solid(%.17g,%.17g,%.17g)", s->color.x, s->color.y, s->color.z);
+    else if (auto c = dynamic_cast<const CheckerTexture *>(t)) {
+        std::printf("checker(");
+        describe_texture(c->black.get());
+        std::printf(",");
+        describe_texture(c->white.get());
+        std::printf(")");
+    } else if (auto im = dynamic_cast<const ImageTexture *>(t)) {
+        unsigned long long sum = 0;
+        for (size_t i = 0; i < im->rgb.size(); ++i) sum = sum * 1315423911ull + im->rgb[i];
+        std::printf("image(%d,%d,%llu)", im->w, im->h, sum);
+    }
+}
+inline void describe(const std::vector<SpritePtr> &sprites, const PerspectiveCamera &cam) {
+    for (const SpritePtr &sp : sprites) {
+        const Geometry *g = sp->geometry_.get();
+        if (auto s = dynamic_cast<const Sphere *>(g)) std::printf("sphere(%.17g)", s->radius);
+        else if (auto r = dynamic_cast<const Rectangle *>(g)) std::printf("rectangle(%.17g,%.17g)", r->width, r->height);
+        else if (auto c = dynamic_cast<const Cube *>(g)) std::printf("cube(%.17g,%.17g,%.17g)", c->width, c->height, c->depth);
+        else if (auto m = dynamic_cast<const ConstantMedium *>(g))
+            std::printf("medium(sphere(%.17g),%.17g)", dynamic_cast<const Sphere *>(m->boundary.get())->radius, m->density);
+        else std::printf("none");
+        std::printf(" ");
+        const Material *mt = sp->material_.get();
+        if (auto l = dynamic_cast<const Lambertian *>(mt)) {
+            std::printf("lambertian(");
+            describe_texture(l->albedo.get());
+            std::printf(")");
+        } else if (auto me = dynamic_cast<const Metal *>(mt)) {
+            std::printf("metal(");
+            describe_texture(me->albedo.get());
+            std::printf(",%.17g)", me->fuzziness);
+        } else if (auto d = dynamic_cast<const Dielectric *>(mt)) std::printf("dielectric(%.17g)", d->refractive);
+        else if (auto dl = dynamic_cast<const DiffuseLight *>(mt)) {
+            std::printf("diffuse_light(");
+            describe_texture(dl->emission.get());
+            std::printf(")");
+        } else if (auto is = dynamic_cast<const Isotropic *>(mt)) {
+            std::printf("isotropic(");
+            describe_texture(is->albedo.get());
+            std::printf(")");
+        } else std::printf("none");
+        for (double v : sp->transform_.a) std::printf(" %.17g", v);
+        std::printf("\n");
+    }
+    std::printf("camera");
+    for (double v : cam.c.eye) std::printf(" %.17g", v);
+    for (double v : cam.c.lower_left) std::printf(" %.17g", v);
+    for (double v : cam.c.horizontal) std::printf(" %.17g", v);
+    for (double v : cam.c.vertical) std::printf(" %.17g", v);
+    std::printf(" %.17g\n", cam.c.lens_radius);
+}
+
+inline int run(const Options &o, const std::vector<SpritePtr> &sprites, const PerspectiveCamera &camera) {
+    if (o.describe) {
+        describe(sprites, camera);
+        auto w = BoundingVolumeHierarchyNode::make(sprites, -1);
+        if (!w) return 1;
+        rt_scene_info i = w->info();
+        std::printf("info prims=%d hoisted=%d nodes=%d child_prims=%d\n", i.n_prims, i.n_hoisted, i.n_nodes, i.n_child_prims);
+        return 0;
+    }
+    auto world = BoundingVolumeHierarchyNode::make(sprites, o.device); // .unwrap() in the reference
+    if (!world) {
+        std::fprintf(stderr, "empty scene\n");
+        return 1;
+    }
+    std::vector<Vec3> buffer = render(*world, camera, o.width, o.height, o.spp, o.depth, o.seed);
+    write_ppm(o.out == "-" ? "/dev/stdout" : o.out, buffer, o.width, o.height); // P3 text like println! in the reference
+    return 0;
+}
+
+} // namespace rtx
+#endif

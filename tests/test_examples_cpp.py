@@ -1,0 +1,100 @@
+"""The three example drivers restated in C++ over the facade (ray-tracer_amd/host): their
+scenes must equal the Python scene descriptions sprite for sprite (CPU), and their P3 output
+must be byte-identical to the Python-driven render of the same parameters (GPU)."""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+BIN = ROOT / "ray-tracer_amd" / "host" / "bin"
+
+
+@pytest.fixture(scope="module")
+def binaries(rt):
+    if not (BIN / "book_one").exists():
+        subprocess.run(["make", "-C", str(ROOT / "ray-tracer_amd" / "host")], check=True, capture_output=True)
+    return BIN
+
+
+def g17(v):
+    return "%.17g" % v
+
+
+def describe_texture(d, t):
+    tex = d.textures[t]
+    if tex[0] == "solid":
+        return "solid(%s)" % ",".join(g17(c) for c in tex[1])
+    if tex[0] == "checker":
+        return "checker(%s,%s)" % (describe_texture(d, tex[1]), describe_texture(d, tex[2]))
+    a = np.ascontiguousarray(tex[1], dtype=np.uint8)
+    s = 0
+    for b in a.reshape(-1).tolist():
+        s = (s * 1315423911 + b) & 0xFFFFFFFFFFFFFFFF
+    return "image(%d,%d,%d)" % (a.shape[1], a.shape[0], s)
+
+
+def describe(d, order=None):
+    lines = []
+    ident = [1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0]
+    for i in (order if order is not None else range(len(d.sprites))):
+        gi, mi, M = d.sprites[i]
+        g = d.geometries[gi]
+        if g[0] == "medium":
+            gs = "medium(sphere(%s),%s)" % (g17(d.geometries[g[1]][1]), g17(g[2]))
+        else:
+            gs = "%s(%s)" % (g[0], ",".join(g17(v) for v in g[1:]))
+        m = d.materials[mi]
+        if m[0] == "dielectric":
+            ms = "dielectric(%s)" % g17(m[1])
+        elif m[0] == "metal":
+            ms = "metal(%s,%s)" % (describe_texture(d, m[1]), g17(m[2]))
+        else:
+            ms = "%s(%s)" % (m[0], describe_texture(d, m[1]))
+        lines.append(" ".join([gs, ms] + [g17(v) for v in (M if M is not None else ident)]))
+    return lines
+
+
+def flat_order(world):
+    out = []
+    for e in world:
+        if isinstance(e, tuple):
+            out.extend(flat_order(e[1]))
+        else:
+            out.append(e)
+    return out
+
+
+@pytest.mark.parametrize("exe,gen,kw,wh", [
+    ("book_one", "book_one", dict(scene_seed=5), (1600, 800)),
+    ("cornell_box", "cornell", dict(), (800, 800)),
+    ("cover", "cover", dict(scene_seed=5), (800, 800)),
+])
+def test_cpp_scene_equals_python_scene(binaries, rt, scenes, exe, gen, kw, wh):
+    out = subprocess.run([str(binaries / exe), "--describe", "--scene-seed", "5"], check=True, capture_output=True, text=True).stdout
+    lines = out.strip().split("\n")
+    d = getattr(scenes, gen)(aspect=wh[0] / wh[1], **kw)
+    order = flat_order(d.world) if d.world is not None else None
+    assert lines[:-2] == describe(d, order)
+    cam = rt.Camera(*d.camera)
+    cam_vals = list(cam.c.eye) + list(cam.c.lower_left) + list(cam.c.horizontal) + list(cam.c.vertical) + [cam.c.lens_radius]
+    assert lines[-2] == "camera " + " ".join(g17(v) for v in cam_vals)
+    info = scenes.build_product(d, device=-1)[0].info()
+    assert lines[-1] == "info prims=%d hoisted=%d nodes=%d child_prims=%d" % (info["n_prims"], info["n_hoisted"], info["n_nodes"],
+                                                                                info["n_child_prims"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exe,gen,W,H,spp", [("book_one", "book_one", 96, 64, 4), ("cornell_box", "cornell", 48, 48, 4),
+                                              ("cover", "cover", 40, 40, 2)])
+def test_cpp_driver_ppm_is_byte_identical(binaries, rt, scenes, gpu_device, tmp_path, exe, gen, W, H, spp):
+    out = tmp_path / "cpp.ppm"
+    subprocess.run([str(binaries / exe), "--width", str(W), "--height", str(H), "--spp", str(spp), "--depth", "50", "--seed", "3",
+                    "--scene-seed", "2", "--out", str(out)], check=True)
+    kw = {} if gen == "cornell" else {"scene_seed": 2}
+    sc, cam = scenes.build_product(getattr(scenes, gen)(aspect=W / H, **kw), device=gpu_device)
+    ref = tmp_path / "py.ppm"
+    rt.write_ppm_p3(ref, sc.render(cam, W, H, spp, 50, seed=3))
+    assert out.read_bytes() == ref.read_bytes()
+    assert out.read_text().startswith(f"P3\n{W} {H}\n255\n")
