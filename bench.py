@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--scene-seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
+    ap.add_argument("--scene", default="book_one", choices=["book_one", "cornell", "cover"],
+                    help="book_one is the headline workload; the others are for measuring BASELINE configs[2], [3]")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path on a box with fewer GPUs (shards staged through host memory)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -94,7 +96,12 @@ def main():
     rt = load_package()
     scenes = importlib.import_module("ray_tracer_amd.scenes")
     W, H, spp, depth = a.width, a.height, a.spp, a.depth
-    desc = scenes.book_one(a.scene_seed, W / H)
+    if a.scene == "book_one":
+        desc = scenes.book_one(a.scene_seed, W / H)
+    elif a.scene == "cornell":
+        desc = scenes.cornell(W / H)
+    else:
+        desc = scenes.cover(a.scene_seed, W / H)
     sc, cam = scenes.build_product(desc, device=local_rank)
     info = sc.info()
 
@@ -156,7 +163,7 @@ def main():
         value = a.steps * total_samples / dt / 1e6
         # algorithmic bytes per sample from the kernel's own traversal counters,
         # measured on the same image at reduced spp with the counting build of the same kernel
-        cspp = min(spp, 8)
+        cspp = min(spp, 64)
         _, cnt = sc.render(cam, W, H, cspp, depth, a.seed, counters=True)
         ns = max(1, cnt["samples"])
         bytes_per_sample = (cnt["nodes_visited"] * info["node_bytes"] + cnt["prims_tested"] * info["prim_bytes"]
@@ -167,14 +174,15 @@ def main():
         # tools/profile.sh; corrected as MI355X_MICROARCH.md prescribes); only valid for the profiled workload
         traffic = None
         tf = ROOT / "profiles" / "pmc_traffic.json"
-        if tf.exists() and (W, H, spp, depth, world) == (1200, 800, 500, 100, 1):
+        if tf.exists() and (a.scene, W, H, spp, depth, world) == ("book_one", 1200, 800, 500, 100, 1):
             traffic = json.load(open(tf))["hbm_bytes_per_launch"]
         res = {
-            "metric": "Msamples/sec (pixels x spp), book-one 1200x800x500spp",
+            "metric": "Msamples/sec (pixels x spp), book-one 1200x800x500spp" if a.scene == "book_one" else f"Msamples/sec (pixels x spp), {a.scene}",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"book-one random-spheres {W}x{H}, {spp} spp, depth {depth} (BASELINE.json configs[1])",
+            "config": {"workload": (f"book-one random-spheres {W}x{H}, {spp} spp, depth {depth} (BASELINE.json configs[1])"
+                                    if a.scene == "book_one" else f"{a.scene} {W}x{H}, {spp} spp, depth {depth}"),
                        "scene_seed": a.scene_seed, "render_seed": a.seed, "n_spheres": info["n_prims"],
                        "bvh_nodes": info["n_nodes"], "sharding": f"8x8 tiles, tile_id % {world}, one RCCL gather"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

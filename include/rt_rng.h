@@ -61,6 +61,11 @@ typedef struct rt_rng {
 } rt_rng;
 
 RT_HD uint64_t rt_mix64(uint64_t z) {
+#if defined(RT_RNG_ABLATE) /* timing experiment only: NOT the contract */
+    z ^= z >> 29;
+    z += z << 17;
+    return z ^ (z >> 31);
+#endif
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);

@@ -354,7 +354,15 @@ int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_render_pa
     for (int pass = 0; pass < n_pass; ++pass) {
         L.s0 = pass * chunk;
         L.s_count = std::min(chunk, p->spp - L.s0);
-        L.jobs_per_tile = (L.s_count + RT_JOB_SPP - 1) / RT_JOB_SPP;
+        // job size: at most RT_JOB_SPP_MAX samples per pixel, smaller when the pass is small so that
+        // every resident wave still draws >= ~32 jobs (end-of-launch tail <= ~3 %)
+        {
+            const long long waves = (long long)per_cu * n_cu * (block / 64);
+            const long long want_jobs = waves * 32;
+            long long js = ((long long)L.s_count * n_owned + want_jobs - 1) / want_jobs;
+            L.job_spp = (int)std::max<long long>(1, std::min<long long>(RT_JOB_SPP_MAX, js));
+        }
+        L.jobs_per_tile = (L.s_count + L.job_spp - 1) / L.job_spp;
         const long long n_jobs = (long long)L.jobs_per_tile * n_owned;
         if (n_jobs > 0x7FFFFFFFll) return fail(RT_ERR_INVALID, "too many jobs in one pass");
         L.n_jobs = (int)n_jobs;

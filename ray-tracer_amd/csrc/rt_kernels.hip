@@ -12,7 +12,7 @@
 //     shade block -- binary64 hit record + Material::scatter, then the next
 //                    segment; a finished path stores its radiance and the lane
 //                    immediately takes the next sample of the wave's job queue
-//                    (jobs = 8x8-pixel tile x RT_JOB_SPP samples, drawn from one
+//                    (jobs = 8x8-pixel tile x job_spp samples, drawn from one
 //                    device-wide atomic counter).
 //   The expensive blocks only run when enough lanes have queued up for them (or
 //   nothing else can run), so each block executes at high SIMD occupancy instead
@@ -41,16 +41,19 @@
 // vote thresholds (lanes).  A block runs when at least this many lanes wait for
 // it, or when no cheaper block has work.
 #ifndef RT_VOTE_SHADE
-#define RT_VOTE_SHADE 40
+#define RT_VOTE_SHADE 48
 #endif
 #ifndef RT_VOTE_LEAF
-#define RT_VOTE_LEAF 32
+#define RT_VOTE_LEAF 16
 #endif
 #ifndef RT_NODE_KEEP
-#define RT_NODE_KEEP 40
+#define RT_NODE_KEEP 8
 #endif
 #ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU 4
+#define RT_WAVES_PER_EU 4 /* spheres-only kernel: 105 VGPRs fit 4 waves per SIMD */
+#endif
+#ifndef RT_WAVES_PER_EU_GENERAL
+#define RT_WAVES_PER_EU_GENERAL 2 /* general kernel (matrices, cubes, media, textures) needs the registers */
 #endif
 
 namespace {
@@ -78,7 +81,7 @@ __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__bui
 extern __shared__ __attribute__((aligned(16))) unsigned char rt_lds[];
 
 template <bool GENERAL, bool MEDIUM, bool TEXTURED, bool LENS, bool COUNT, bool LDSNODES>
-__global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void render_kernel(const RtLaunch L) {
+__global__ __launch_bounds__(RT_BLOCK, (GENERAL ? RT_WAVES_PER_EU_GENERAL : RT_WAVES_PER_EU)) void render_kernel(const RtLaunch L) {
     uint32_t *stack_mem = reinterpret_cast<uint32_t *>(rt_lds);
     LdsStack st;
     st.base = stack_mem + threadIdx.x;
@@ -167,8 +170,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES_PER_EU) void render_kernel(const
                     const uint32_t ty = tile / (uint32_t)L.tiles_x, tx = tile - ty * (uint32_t)L.tiles_x;
                     job_x0 = tx * RT_TILE_EDGE;
                     job_y0 = ty * RT_TILE_EDGE;
-                    job_s_first = sub * RT_JOB_SPP;
-                    const uint32_t nspp = min((uint32_t)RT_JOB_SPP, (uint32_t)L.s_count - job_s_first);
+                    job_s_first = sub * (uint32_t)L.job_spp;
+                    const uint32_t nspp = min((uint32_t)L.job_spp, (uint32_t)L.s_count - job_s_first);
                     job_left = nspp * RT_TILE_PIXELS;
                     job_next = 0u;
                     job_slot0 = (k * (uint32_t)L.s_count + job_s_first) * RT_TILE_PIXELS;

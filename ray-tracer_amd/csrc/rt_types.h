@@ -10,7 +10,7 @@
 #define RT_TILE_PIXELS 64
 #define RT_STACK_DEPTH 24   /* traversal stack entries per lane; the builder bounds the tree depth to this */
 #define RT_MAX_HOISTED 4    /* scene-spanning prims tested up front instead of through the BVH */
-#define RT_JOB_SPP 32       /* samples per pixel in one job (job = one 8x8 tile x RT_JOB_SPP samples) */
+#define RT_JOB_SPP_MAX 32   /* samples per pixel in one job at most (job = one 8x8 tile x job_spp samples) */
 #define RT_NO_MATERIAL 0xFFFFFFFFu
 
 // 16-bit child references (stack entries pack one next to a truncated f32 tnear)
@@ -125,7 +125,7 @@ struct RtLaunch {
     int32_t shard_index, shard_count, n_owned_tiles;
     // this pass: samples [s0, s0 + s_count) of every owned pixel
     int32_t s0, s_count;
-    int32_t jobs_per_tile, n_jobs;
+    int32_t job_spp, jobs_per_tile, n_jobs; // job_spp adapts so that every wave sees >= ~32 jobs
     unsigned int *job_counter; // zeroed before the launch
     double *samples;           // per-sample radiance of this pass: [owned tile][s - s0][pixel][4] (32-byte records)
     RtCounters *counters;      // may be null

@@ -129,6 +129,14 @@ def test_edge_cases(rt, scenes, oracle, gpu_device):
     s2.sprite(s2.sphere(1.0), None, scenes.mat4_translation((0, 0, 3)))
     s2.commit(gpu_device)
     assert np.array_equal(s2.render(c, 16, 16, 2, 10), np.zeros((16, 16, 3)))
+    # a light enclosure (hoisted) + ONE small sphere: the BVH root is a bare leaf reference
+    d1 = scenes.SceneDesc()
+    d1.sprite(d1.geom("sphere", 1.0), d1.lambertian_rgb((0.5, 0.5, 0.5)), scenes.mat4_translation((0, 0, 5)))
+    d1.sprite(d1.geom("sphere", 100.0), d1.mat("diffuse_light", d1.tex_solid((1, 1, 1))), None)
+    d1.camera = ((0, 0, 0), (0, 0, 5), (0, 1, 0), 0.6, 1.0, 1.0, 0.0)
+    sc1, cam1 = scenes.build_product(d1, device=gpu_device)
+    assert sc1.info()["n_hoisted"] == 1 and sc1.info()["n_nodes"] == 0
+    assert np.array_equal(sc1.render(cam1, 24, 24, 8, 50, seed=1), oracle.build_oracle(d1).render(24, 24, 8, 50, seed=1, iterative=True))
     # five separated spheres: nothing hoisted, pure BVH path
     d5 = scenes.SceneDesc()
     for i in range(5):
