@@ -12,12 +12,15 @@
  * reproduce its own image.  "Identical RNG seeds" therefore means: oracle and
  * kernel consume THIS generator, in the program order documented below.
  *
- * Generator: SplitMix64 (Steele, Lea, Flood 2014) used in counter mode.
- *   draw n (n >= 1) of stream `stream` under `seed`:
- *       x_n = mix64( base + n * GAMMA ),   base = mix64(seed) + (stream << 24) * GAMMA
- *   For a fixed seed the map (stream, n) -> state is a bijection, so no two
- *   samples ever share a sub-sequence.  A stream may draw < 2^23 sequential
- *   numbers; counters >= 2^23 are the "keyed" domain used by ConstantMedium.
+ * Generator: one xoroshiro128+ stream (Blackman & Vigna 2018; a=24, b=16, c=37) per
+ * sample, seeded -- as its authors recommend -- by SplitMix64 (Steele, Lea, Flood 2014):
+ *       base   = mix64(seed) + (stream << 24) * GAMMA          (injective in `stream`)
+ *       s0, s1 = mix64(base + GAMMA), mix64(base + 2*GAMMA)    (SplitMix64 outputs 1, 2 of `base`)
+ *       draw   : r = s0 + s1;  s1 ^= s0;  s0 = rotl(s0,24) ^ s1 ^ (s1 << 16);  s1 = rotl(s1,37)
+ *   Only the top 53 / 52 bits of a draw are used (the weak low bits of the + scrambler
+ *   never are).  xoroshiro needs no multiplies: 64-bit multiplies are quarter-rate on the
+ *   CDNA4 VALU and the rejection samplers draw ~6 numbers per diffuse bounce.
+ *   "Keyed" draws (ConstantMedium) stay counter-based: mix64(base + n * GAMMA), n >= 2^23.
  *
  * Float conversions restate rand 0.7.x (the newest series that still has the
  * two-argument `gen_range(low, high)` the reference calls):
@@ -56,16 +59,11 @@
 #define RT_RNG_SCENE_STREAM ((1ull << 40) - 1ull)
 
 typedef struct rt_rng {
-    uint64_t base; /* mix64(seed) + (stream << 24) * GAMMA */
-    uint64_t s;    /* base + n * GAMMA after n sequential draws */
+    uint64_t base;   /* mix64(seed) + (stream << 24) * GAMMA: key of the stream (keyed draws) */
+    uint64_t s0, s1; /* xoroshiro128+ state */
 } rt_rng;
 
 RT_HD uint64_t rt_mix64(uint64_t z) {
-#if defined(RT_RNG_ABLATE) /* timing experiment only: NOT the contract */
-    z ^= z >> 29;
-    z += z << 17;
-    return z ^ (z >> 31);
-#endif
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
@@ -75,16 +73,33 @@ RT_HD uint64_t rt_rng_base(uint64_t seed, uint64_t stream) {
     return rt_mix64(seed) + (stream << RT_RNG_STREAM_SHIFT) * RT_RNG_GAMMA;
 }
 
+RT_HD uint64_t rt_rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+/* seed the xoroshiro128+ state from the stream key */
+RT_HD void rt_rng_seed_state(uint64_t base, uint64_t *s0, uint64_t *s1) {
+    *s0 = rt_mix64(base + RT_RNG_GAMMA);
+    *s1 = rt_mix64(base + 2ull * RT_RNG_GAMMA);
+    if ((*s0 | *s1) == 0ull) *s0 = RT_RNG_GAMMA; /* the all-zero state is the one fixed point */
+}
+
 RT_HD void rt_rng_init(rt_rng *g, uint64_t seed, uint64_t stream) {
     g->base = rt_rng_base(seed, stream);
-    g->s = g->base;
+    rt_rng_seed_state(g->base, &g->s0, &g->s1);
+}
+
+/* one xoroshiro128+ step on explicit state words */
+RT_HD uint64_t rt_xoroshiro_next(uint64_t *s0p, uint64_t *s1p) {
+    const uint64_t s0 = *s0p;
+    uint64_t s1 = *s1p;
+    const uint64_t r = s0 + s1;
+    s1 ^= s0;
+    *s0p = rt_rotl64(s0, 24) ^ s1 ^ (s1 << 16);
+    *s1p = rt_rotl64(s1, 37);
+    return r;
 }
 
 /* next sequential 64-bit draw */
-RT_HD uint64_t rt_rng_next(rt_rng *g) {
-    g->s += RT_RNG_GAMMA;
-    return rt_mix64(g->s);
-}
+RT_HD uint64_t rt_rng_next(rt_rng *g) { return rt_xoroshiro_next(&g->s0, &g->s1); }
 
 /* keyed draw: independent of how many sequential draws were made */
 RT_HD uint64_t rt_rng_keyed_from_base(uint64_t base, uint32_t segment, uint32_t slot) {

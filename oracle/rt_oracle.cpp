@@ -1138,6 +1138,9 @@ void orc_kat_rng_u64(uint64_t seed, uint64_t stream, int n, uint64_t *out) {
     rt_rng_init(&g, seed, stream);
     for (int i = 0; i < n; ++i) out[i] = rt_rng_next(&g);
 }
+void orc_kat_xoroshiro(uint64_t s0, uint64_t s1, int n, uint64_t *out) {
+    for (int i = 0; i < n; ++i) out[i] = rt_xoroshiro_next(&s0, &s1);
+}
 void orc_kat_random_in_unit_sphere(uint64_t seed, uint64_t stream, double out[3]) {
     Ctx c;
     rt_rng_init(&c.rng, seed, stream);

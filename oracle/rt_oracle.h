@@ -118,6 +118,8 @@ int orc_kat_world_hit(orc_scene *, const double o[3], const double d[3], uint64_
 int orc_kat_world_node_count(orc_scene *);
 /* first n sequential draws of (seed, stream) as raw u64 */
 void orc_kat_rng_u64(uint64_t seed, uint64_t stream, int n, uint64_t *out);
+/* n xoroshiro128+ steps from an explicit state (include/rt_rng.h) */
+void orc_kat_xoroshiro(uint64_t s0, uint64_t s1, int n, uint64_t *out);
 /* randomInUnitSphere / randomInUnitDisk (src/util.rs:6-15,27-42) */
 void orc_kat_random_in_unit_sphere(uint64_t seed, uint64_t stream, double out[3]);
 void orc_kat_random_in_unit_disk(uint64_t seed, uint64_t stream, double out[3]);

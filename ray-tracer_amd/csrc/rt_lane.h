@@ -69,23 +69,21 @@ struct Rec { // HitRecord, src/ray.rs:36-43 (material lives on the prim)
 
 // ---- per-sample random numbers: include/rt_rng.h ----
 struct Rng {
-    uint64_t base, s;
+    uint64_t base;   // stream key (keyed medium draws)
+    uint64_t s0, s1; // xoroshiro128+ state
     unsigned long long draws;
 };
 RT_HD double rng_unit53(Rng &g) { // rand::random::<f64>()
-    g.s += RT_RNG_GAMMA;
     ++g.draws;
-    return rt_u64_to_unit53(rt_mix64(g.s));
+    return rt_u64_to_unit53(rt_xoroshiro_next(&g.s0, &g.s1));
 }
 RT_HD double rng_range01(Rng &g) { // gen_range(0.0, 1.0)
-    g.s += RT_RNG_GAMMA;
     ++g.draws;
-    return rt_u64_to_range01(rt_mix64(g.s));
+    return rt_u64_to_range01(rt_xoroshiro_next(&g.s0, &g.s1));
 }
 RT_HD double rng_range11(Rng &g) { // gen_range(-1.0, 1.0)
-    g.s += RT_RNG_GAMMA;
     ++g.draws;
-    return rt_u64_to_range11(rt_mix64(g.s));
+    return rt_u64_to_range11(rt_xoroshiro_next(&g.s0, &g.s1));
 }
 RT_HD V3 random_in_unit_sphere(Rng &g) { // src/util.rs:6-15
     V3 p = mk(1.0, 1.0, 1.0);
@@ -102,7 +100,9 @@ RT_HD V3 random_in_unit_disk(Rng &g) { // src/util.rs:27-42
         double a = rng_range11(g);
         double b = rng_range11(g);
         V3 p = mk(a, b, 0.0);
-        if (length(p) >= 1.0) continue;
+        // `p.length() >= 1.0`: sqrt is monotone and exact at 1, so sqrt(s) >= 1 <=> s >= 1 for every
+        // binary64 s (checked in tests/test_oracle_kat.py); the square root itself is never needed
+        if (a * a + b * b >= 1.0) continue;
         return p;
     }
 }
@@ -576,7 +576,7 @@ RT_HD void start_sample(const RtLaunch &L, uint32_t x, uint32_t y, uint32_t s, P
     const uint64_t pixel = (uint64_t)y * (uint64_t)L.width + (uint64_t)x;
     const uint64_t stream = pixel * (uint64_t)L.spp + (uint64_t)s;
     ps->g.base = L.seed_mix + (stream << RT_RNG_STREAM_SHIFT) * RT_RNG_GAMMA;
-    ps->g.s = ps->g.base;
+    rt_rng_seed_state(ps->g.base, &ps->g.s0, &ps->g.s1);
     ps->g.draws = 0;
     double u = ((double)x + rng_range01(ps->g)) / (double)L.width;
     double v = ((double)y + rng_range01(ps->g)) / (double)L.height;

@@ -40,11 +40,22 @@ class HostRng:
 
     def __init__(self, seed: int, stream: int = SCENE_STREAM):
         self.base = (mix64(seed) + ((stream << 24) & MASK) * GAMMA) & MASK
-        self.s = self.base
+        self.s0 = mix64((self.base + GAMMA) & MASK)
+        self.s1 = mix64((self.base + 2 * GAMMA) & MASK)
+        if (self.s0 | self.s1) == 0:
+            self.s0 = GAMMA
 
-    def next_u64(self) -> int:
-        self.s = (self.s + GAMMA) & MASK
-        return mix64(self.s)
+    @staticmethod
+    def _rotl(x: int, k: int) -> int:
+        return ((x << k) | (x >> (64 - k))) & MASK
+
+    def next_u64(self) -> int:  # xoroshiro128+ (a=24, b=16, c=37)
+        s0, s1 = self.s0, self.s1
+        r = (s0 + s1) & MASK
+        s1 ^= s0
+        self.s0 = self._rotl(s0, 24) ^ s1 ^ ((s1 << 16) & MASK)
+        self.s1 = self._rotl(s1, 37)
+        return r
 
     def gen_range(self, low: float, high: float) -> float:
         scale = high - low

@@ -66,6 +66,7 @@ _sig("orc_kat_camera_ray", None, [_VP, _D, _D, _U64, _U64, _DP])
 _sig("orc_kat_world_hit", _I, [_VP, _DP, _DP, _U64, _U64, _DP])
 _sig("orc_kat_world_node_count", _I, [_VP])
 _sig("orc_kat_rng_u64", None, [_U64, _U64, _I, C.POINTER(C.c_uint64)])
+_sig("orc_kat_xoroshiro", None, [_U64, _U64, _I, C.POINTER(C.c_uint64)])
 _sig("orc_kat_random_in_unit_sphere", None, [_U64, _U64, _DP])
 _sig("orc_kat_random_in_unit_disk", None, [_U64, _U64, _DP])
 _sig("orc_kat_texture_value", None, [_VP, _I, _D, _D, _DP])
