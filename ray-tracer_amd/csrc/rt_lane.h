@@ -323,9 +323,16 @@ struct Trav {
     float fx, fy, fz;    // -(o/d - pad): exit planes
 };
 
-RT_HD float up32(double t) { // >= t in binary32
+RT_HD float up32(double t) { // >= t in binary32, with room for the ~3e-7 relative error of a computed tnear
     float f = (float)t;
-    return f * 1.0000005f;
+    return f * 1.000001f;
+}
+RT_HD float rcp32(float x) { // 1/x to 1 ulp: v_rcp_f32 on the device (culling only; covered by the slack below)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
 }
 RT_HD float bits_f32(uint32_t u) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -365,9 +372,9 @@ RT_HD void trav_pop(Trav &tv, Stack &st) {
 template <bool GENERAL, bool MEDIUM, bool UV, class Stack>
 RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack &st) {
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
-    tv.idx = 1.0f / (float)d.x;
-    tv.idy = 1.0f / (float)d.y;
-    tv.idz = 1.0f / (float)d.z;
+    tv.idx = rcp32((float)d.x);
+    tv.idy = rcp32((float)d.y);
+    tv.idz = rcp32((float)d.z);
     // the binary32 ray is displaced from the binary64 one by <= 2^-24 (|o| + t|d|) per axis;
     // the box pad covers the |o + t d| share, this pad the |o| share (>2x margin each)
     const float e = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) * 0x1p-21f + 1e-30f;
@@ -416,7 +423,7 @@ RT_HD void trav_node_step(const RtNode *nodes, Trav &tv, Stack &st) {
         tmax[c] = fminf(fminf(fmaxf(cx, dx), fmaxf(cy, dy)), fminf(fmaxf(cz, dz), tv.best32));
     }
     // slack for the rounding of the slab arithmetic itself
-    const bool h0 = tmin[0] <= tmax[0] * 1.000001f, h1 = tmin[1] <= tmax[1] * 1.000001f;
+    const bool h0 = tmin[0] <= tmax[0] * 1.000002f, h1 = tmin[1] <= tmax[1] * 1.000002f;
     const bool one_first = tmin[1] < tmin[0];
     const bool both = h0 && h1;
     const uint32_t first = both ? (one_first ? c1 : c0) : (h0 ? c0 : c1);
