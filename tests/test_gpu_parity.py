@@ -235,3 +235,33 @@ def test_full_size_cover_800x800(rt, scenes, oracle, gpu_device):
     sc, cam = scenes.build_product(desc, device=gpu_device)
     img = _subset_check(sc, cam, desc, oracle, W, H, 16, 100, 1, n_pix=24, max_bad=2)
     assert np.isfinite(img).all() and img.min() >= 0.0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_scenes_match_oracle(rt, scenes, oracle, gpu_device, seed):
+    """Random transforms (incl. non-rigid), cubes, media, textures, lens: general kernel vs oracle."""
+    from test_random_scenes import random_scene
+    d = random_scene(scenes, seed)
+    sc, cam = scenes.build_product(d, device=gpu_device)
+    img = sc.render(cam, 40, 30, 4, 40, seed=seed + 100)
+    ref = oracle.build_oracle(d, bvh_seed=seed).render(40, 30, 4, 40, seed=seed + 100, iterative=True, nthreads=8)
+    _close(img, ref, max_bad=4)
+
+
+def test_config5_shape_3840x2160_sharded_multipass(rt, scenes, oracle, gpu_device, monkeypatch):
+    """configs[4] shape: 3840x2160 tile-sharded 8 ways (the shards rendered one after another on this one
+    GPU), sample workspace capped so that every shard needs several passes; 6 of the 2000 spp."""
+    W, H, spp, depth = 3840, 2160, 6, 100
+    monkeypatch.setenv("RT_SAMPLE_WORKSPACE_MB", "96")  # 96 MiB / (16200 tiles * 64 * 32 B) = 3 spp per pass
+    desc = scenes.book_one(1, W / H)
+    sc, cam = scenes.build_product(desc, device=gpu_device)
+    img = np.zeros((H, W, 3))
+    for r in range(8):
+        img += sc.render(cam, W, H, spp, depth, 1, shard=(r, 8))
+    assert np.isfinite(img).all() and img.min() >= 0.0 and img.max() <= 1.0 + 1e-12
+    o = oracle.build_oracle(desc)
+    rng = np.random.default_rng(5)
+    for _ in range(64):
+        x, y = int(rng.integers(W)), int(rng.integers(H))
+        ref = o.render(W, H, spp, depth, 1, region=(x, y, x + 1, y + 1), iterative=True)[y, x]
+        assert np.array_equal(img[y, x], ref), (x, y)

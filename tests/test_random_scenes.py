@@ -1,0 +1,77 @@
+"""Randomised scenes: the host-compiled lane program (flattener + SAH BVH + binary32 culling
++ hoisting + every primitive / material kind) against the oracle, bit for bit, on scenes
+nobody hand-picked.  CPU only."""
+import math
+
+import numpy as np
+import pytest
+
+
+def random_scene(scenes, seed):
+    rng = np.random.default_rng(seed)
+    d = scenes.SceneDesc()
+    tex = [d.tex_solid(rng.uniform(0.05, 0.95, 3)) for _ in range(4)]
+    d.textures.append(("checker", tex[0], tex[1]))
+    tex.append(len(d.textures) - 1)
+    d.textures.append(("image", rng.integers(0, 256, (6, 9, 3), dtype=np.uint8)))
+    tex.append(len(d.textures) - 1)
+
+    def material():
+        k = rng.integers(0, 5)
+        t = int(tex[rng.integers(len(tex))])
+        if k == 0:
+            return d.mat("lambertian", t)
+        if k == 1:
+            return d.mat("metal", t, float(rng.choice([0.0, rng.uniform(0.05, 0.9)])))
+        if k == 2:
+            return d.mat("dielectric", float(rng.uniform(1.1, 2.0)))
+        if k == 3:
+            return d.mat("isotropic", t)
+        return d.mat("diffuse_light", t)
+
+    def transform(pos):
+        T = scenes.mat4_translation(pos)
+        c = rng.integers(0, 4)
+        if c == 0:
+            return T
+        axis = [(1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)][rng.integers(3)]
+        M = scenes.mat4_multiplied(T, scenes.mat4_rotation(float(rng.uniform(-3, 3)), axis))
+        if c == 3:  # non-rigid: anisotropic scale (quirk Q5: normals use M, directions not renormalised)
+            S = [0.0] * 16
+            S[0], S[5], S[10], S[15] = float(rng.uniform(0.5, 2)), float(rng.uniform(0.5, 2)), float(rng.uniform(0.5, 2)), 1.0
+            M = scenes.mat4_multiplied(M, S)
+        return M
+
+    n = int(rng.integers(3, 40))
+    for _ in range(n):
+        pos = rng.uniform(-6, 6, 3) + np.array([0, 0, 12.0])
+        g = rng.integers(0, 10)
+        if g < 5:
+            geo = d.geom("sphere", float(rng.uniform(0.2, 1.5)))
+        elif g < 7:
+            geo = d.geom("rectangle", float(rng.uniform(0.5, 4)), float(rng.uniform(0.5, 4)))
+        elif g < 9:
+            geo = d.geom("cube", float(rng.uniform(0.5, 2)), float(rng.uniform(0.5, 2)), float(rng.uniform(0.5, 2)))
+        else:
+            geo = d.geom("medium", d.geom("sphere", float(rng.uniform(0.5, 2.0))), float(rng.uniform(0.1, 2.0)))
+        mat = None if rng.random() < 0.05 else material()
+        if d.geometries[geo][0] == "medium":
+            mat = d.mat("isotropic", int(tex[rng.integers(4)]))
+        d.sprite(geo, mat, transform(pos))
+    if rng.random() < 0.7:  # enclosing light (gets hoisted), sometimes a big ground sphere too
+        d.sprite(d.geom("sphere", 80.0), d.mat("diffuse_light", int(tex[0])), None)
+    if rng.random() < 0.5:
+        d.sprite(d.geom("sphere", 300.0), d.mat("lambertian", int(tex[1])), scenes.mat4_translation((0.0, -306.0, 12.0)))
+    d.camera = ((0.0, 0.5, -2.0), (0.0, 0.0, 12.0), (0.0, 1.0, 0.0), 0.9, 4 / 3, 10.0, float(rng.choice([0.0, 0.05])))
+    return d
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scene_bit_exact(scenes, oracle, lane_emul, seed):
+    d = random_scene(scenes, seed)
+    sc, cam = scenes.build_product(d, device=-1)
+    img, cnt, high = lane_emul.render(sc, cam, 32, 24, 3, 40, seed=seed + 100)
+    ref, ocnt = oracle.build_oracle(d, bvh_seed=seed).render(32, 24, 3, 40, seed=seed + 100, iterative=True, nthreads=4, counters=True)
+    assert np.array_equal(img, ref, equal_nan=True)
+    assert cnt["segments"] == ocnt["segments"]
+    assert high <= 24
