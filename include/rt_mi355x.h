@@ -24,9 +24,12 @@
  *   - images: linear radiance, double, layout [y][x][3] with y UP (row 0 is the
  *     bottom row) exactly like `buffer[y][x]` in examples/book-one.rs:53,87.
  *   - all arithmetic on the path is IEEE binary64 like the reference.
- *   - the scene is immutable after rt_scene_commit; rt_render* may be called
- *     concurrently on a committed scene (the traits are Send + Sync upstream,
- *     src/ray.rs:85).
+ *   - the scene is immutable after rt_scene_commit.  rt_render may be called from any
+ *     number of threads on one committed scene (the traits are Send + Sync upstream,
+ *     src/ray.rs:85); calls on the same scene are serialised because they share its
+ *     per-sample workspace -- commit one scene per device for parallel renders.
+ *     rt_render_tiles_device is asynchronous: issue the calls of one scene on one
+ *     stream (or order them yourself).
  */
 #ifndef RT_MI355X_H
 #define RT_MI355X_H

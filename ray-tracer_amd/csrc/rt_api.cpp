@@ -317,7 +317,7 @@ int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_render_pa
     const size_t need = bytes_per_spp * (size_t)chunk;
     if (need > s->samples_bytes) {
         if (s->d_samples) {
-            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipDeviceSynchronize()); // an earlier render (any stream) may still read the old workspace
             HIP_TRY(hipFree(s->d_samples));
             s->d_samples = nullptr;
             s->samples_bytes = 0;
@@ -339,10 +339,20 @@ int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_render_pa
     // keep 16 waves per CU resident: (1024 / block) workgroups, each with its own node copy
     const int ldsnodes = node_bytes > 0 && (1024u / block) * (stack_bytes + node_bytes) <= 160u * 1024u && !(no_lds && *no_lds == '1');
     const unsigned lds_bytes = stack_bytes + (ldsnodes ? node_bytes : 0u);
-    int per_cu = 0, n_cu = 0;
-    int rc = rt_persistent_blocks(feat, lens, count, ldsnodes, lds_bytes, &per_cu, &n_cu);
-    if (rc != 0) return hip_fail((hipError_t)rc, "occupancy query");
-    if (per_cu < 1) per_cu = 1;
+    int per_cu = 0, n_cu = 0, rc = 0;
+    const unsigned occ_key = feat | (lens ? 8u : 0u) | (count ? 16u : 0u) | (ldsnodes ? 32u : 0u);
+    if (s->occ_key == occ_key && s->occ_lds == lds_bytes) {
+        per_cu = s->occ_per_cu;
+        n_cu = s->occ_n_cu;
+    } else {
+        rc = rt_persistent_blocks(feat, lens, count, ldsnodes, lds_bytes, &per_cu, &n_cu);
+        if (rc != 0) return hip_fail((hipError_t)rc, "occupancy query");
+        if (per_cu < 1) per_cu = 1;
+        s->occ_key = occ_key;
+        s->occ_lds = lds_bytes;
+        s->occ_per_cu = per_cu;
+        s->occ_n_cu = n_cu;
+    }
     L.samples = (double *)s->d_samples;
     L.counters = count ? (RtCounters *)d_counters : nullptr;
     const int n_pass = (p->spp + chunk - 1) / chunk;
@@ -401,6 +411,7 @@ int rt_last_kernel_ms(rt_scene *s, float *ms) {
 int rt_render(rt_scene *s, const rt_camera *cam, const rt_render_params *p, double *out_rgb, rt_counters *counters) {
     if (int e = check_params(s, cam, p)) return e;
     if (!out_rgb) return fail(RT_ERR_INVALID, "null output buffer");
+    std::lock_guard<std::mutex> render_lock(s->render_mu); // one render at a time per scene (shared workspace)
     HIP_TRY(hipSetDevice(s->device));
     const int n_owned = rt_shard_tile_count(p->width, p->height, p->shard_index, p->shard_count);
     if (n_owned < 0) return n_owned;
@@ -422,7 +433,7 @@ int rt_render(rt_scene *s, const rt_camera *cam, const rt_render_params *p, doub
     std::vector<double> host(n_doubles);
     if (rc == RT_OK) rc = rt_render_tiles_device(s, cam, &q, d_out, d_cnt, nullptr);
     if (rc == RT_OK) {
-        hipError_t e = hipDeviceSynchronize();
+        hipError_t e = hipStreamSynchronize(nullptr);
         if (e != hipSuccess) rc = hip_fail(e, "render_kernel execution");
     }
     if (rc == RT_OK) {

@@ -19,7 +19,11 @@ struct rt_scene {
     void *d_nodes = nullptr, *d_prim_meta = nullptr, *d_prim_geo = nullptr, *d_prim_extra = nullptr, *d_xforms = nullptr,
          *d_materials = nullptr, *d_textures = nullptr, *d_blob = nullptr;
     size_t device_bytes = 0;
-    std::mutex mu;
+    std::mutex mu;        // guards the fields below
+    std::mutex render_mu; // serialises rt_render calls: they share the sample workspace
+    // cached occupancy query of the last kernel variant used
+    unsigned occ_key = 0xFFFFFFFFu, occ_lds = 0;
+    int occ_per_cu = 0, occ_n_cu = 0;
     // per-sample radiance workspace (grown on demand, reused between renders) + job counter
     void *d_samples = nullptr;
     size_t samples_bytes = 0;

@@ -137,7 +137,6 @@ def book_one(scene_seed: int = 1, aspect: float = 1.5) -> SceneDesc:
     sph1000, sph2000, sph02, sph1 = d.geom("sphere", 1000.0), d.geom("sphere", 2000.0), d.geom("sphere", 0.2), d.geom("sphere", 1.0)
     d.sprite(sph1000, d.lambertian_rgb((0.5, 0.5, 0.5)), mat4_translation((0.0, -1000.0, 0.0)))  # ground
     d.sprite(sph2000, d.mat("diffuse_light", d.tex_solid((0.5, 0.7, 1.0))), None)                # sky sphere
-    glass = None
     for a in range(-11, 11):
         for b in range(-11, 11):
             which = g.gen_range(0.0, 1.0)

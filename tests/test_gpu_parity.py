@@ -265,3 +265,23 @@ def test_config5_shape_3840x2160_sharded_multipass(rt, scenes, oracle, gpu_devic
         x, y = int(rng.integers(W)), int(rng.integers(H))
         ref = o.render(W, H, spp, depth, 1, region=(x, y, x + 1, y + 1), iterative=True)[y, x]
         assert np.array_equal(img[y, x], ref), (x, y)
+
+
+def test_concurrent_renders_on_one_scene(rt, scenes, gpu_device):
+    """The reference's world is Send + Sync; rt_render from several threads must give the same images."""
+    import threading
+    d = scenes.book_one(1, 1.5)
+    sc, cam = scenes.build_product(d, device=gpu_device)
+    ref = {s: sc.render(cam, 96, 64, 8, 50, seed=s) for s in (1, 2, 3, 4)}
+    out = {}
+
+    def work(seed):
+        for _ in range(3):
+            out[seed] = sc.render(cam, 96, 64, 8, 50, seed=seed)
+    th = [threading.Thread(target=work, args=(s,)) for s in ref]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for s in ref:
+        assert np.array_equal(out[s], ref[s])
