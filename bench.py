@@ -109,8 +109,13 @@ def main():
     pad_tiles = max(n_tiles)
     mine = torch.zeros(pad_tiles * 64 * 3, dtype=torch.float64, device=dev)
     gathered = torch.zeros(world * pad_tiles * 64 * 3, dtype=torch.float64, device=dev) if rank == 0 else None
-    image = torch.zeros(H * W * 3, dtype=torch.float64, device=dev) if rank == 0 else None
-    host_image = torch.zeros(H * W * 3, dtype=torch.float64).pin_memory() if rank == 0 else None
+    # rank 0: double-buffered image + a copy stream, so the device->host copy of step k overlaps the render of
+    # step k+1 (every copy still completes inside the timed region: sync() waits for all streams)
+    images = [torch.zeros(H * W * 3, dtype=torch.float64, device=dev) for _ in range(2)] if rank == 0 else None
+    host_images = [torch.zeros(H * W * 3, dtype=torch.float64).pin_memory() for _ in range(2)] if rank == 0 else None
+    copy_stream = torch.cuda.Stream(device=dev) if rank == 0 else None
+    copy_done = [torch.cuda.Event() for _ in range(2)] if rank == 0 else None
+    step_no = [0]
 
     def step():
         stream = torch.cuda.current_stream().cuda_stream
@@ -125,9 +130,17 @@ def main():
             if rank == 0:
                 gathered.copy_(torch.cat(hl))
         if rank == 0:
+            b = step_no[0] & 1
+            step_no[0] += 1
             src = gathered if world > 1 else mine
-            rt.unpack_tiles_device(src.data_ptr(), pad_tiles, world, W, H, image.data_ptr(), stream)
-            host_image.copy_(image, non_blocking=True)
+            torch.cuda.current_stream().wait_event(copy_done[b])  # the copy that last read images[b] has finished
+            rt.unpack_tiles_device(src.data_ptr(), pad_tiles, world, W, H, images[b].data_ptr(), stream)
+            unpacked = torch.cuda.Event()
+            unpacked.record()
+            copy_stream.wait_event(unpacked)
+            with torch.cuda.stream(copy_stream):
+                host_images[b].copy_(images[b], non_blocking=True)
+                copy_done[b].record()
 
     def sync():
         if world > 1:
@@ -199,7 +212,8 @@ def main():
         }
         if a.check:
             whole = sc.render(cam, W, H, spp, depth, a.seed)
-            res["image_matches_single_gpu"] = bool(np.array_equal(host_image.numpy().reshape(H, W, 3), whole))
+            last = host_images[(step_no[0] - 1) & 1]
+            res["image_matches_single_gpu"] = bool(np.array_equal(last.numpy().reshape(H, W, 3), whole))
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(desc, W, H, depth, a.seed, a.cpu_seconds)
         else:
