@@ -277,7 +277,7 @@ class Scene:
     def render(self, cam: "Camera", width, height, spp, max_depth, seed=1, shard=(0, 1), counters=False):
         """rt_render -> (H, W, 3) float64 image, y up (row 0 = bottom); optionally counters dict."""
         p = rt_render_params(width, height, spp, max_depth, seed, shard[0], shard[1], 0)
-        out = np.zeros((height, width, 3))
+        out = np.zeros((max(height, 1), max(width, 1), 3))  # the library validates the real values
         cnt = rt_counters() if counters else None
         _check(lib().rt_render(self._h, C.byref(cam.c), C.byref(p), _dp(out), C.byref(cnt) if counters else None))
         return (out, cnt.as_dict()) if counters else out

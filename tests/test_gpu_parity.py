@@ -285,3 +285,33 @@ def test_concurrent_renders_on_one_scene(rt, scenes, gpu_device):
         t.join()
     for s in ref:
         assert np.array_equal(out[s], ref[s])
+
+
+@pytest.mark.parametrize("W,H,spp,world", [(1, 1, 1, 1), (1, 1, 37, 3), (7, 3, 2, 5), (9, 17, 5, 8), (64, 8, 1, 16)])
+def test_tiny_images_and_more_shards_than_tiles(rt, scenes, oracle, gpu_device, W, H, spp, world):
+    d = scenes.book_one(6, W / H)
+    sc, cam = scenes.build_product(d, device=gpu_device)
+    ref = oracle.build_oracle(d).render(W, H, spp, 30, seed=11, iterative=True)
+    acc = np.zeros_like(ref)
+    owned = 0
+    for r in range(world):
+        n = rt.shard_tile_count(W, H, r, world)
+        owned += n
+        part = sc.render(cam, W, H, spp, 30, seed=11, shard=(r, world))
+        if n == 0:
+            assert not part.any()
+        acc += part
+    assert owned == ((W + 7) // 8) * ((H + 7) // 8)
+    assert np.array_equal(acc, ref)
+
+
+def test_bad_arguments_are_errors_not_crashes(rt, scenes, gpu_device):
+    sc, cam = scenes.build_product(scenes.book_one(1, 1.5), device=gpu_device)
+    for kw in (dict(width=0), dict(height=-1), dict(spp=0), dict(max_depth=-1), dict(shard=(2, 2)), dict(shard=(0, 0))):
+        args = dict(width=16, height=16, spp=1, max_depth=5, shard=(0, 1))
+        args.update(kw)
+        with pytest.raises(rt.RtError) as e:
+            sc.render(cam, args["width"], args["height"], args["spp"], args["max_depth"], 1, shard=args["shard"])
+        assert e.value.code == -1
+    with pytest.raises(rt.RtError):
+        sc.render(cam, 1 << 15, 1 << 15, 1 << 12, 5)  # >= 2^40 sample streams
