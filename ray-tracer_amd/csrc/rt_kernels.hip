@@ -49,6 +49,16 @@
 #ifndef RT_NODE_KEEP
 #define RT_NODE_KEEP 8
 #endif
+// the general kernel (matrix sprites, cubes, media, textures) has much heavier leaf tests
+#ifndef RT_VOTE_SHADE_G
+#define RT_VOTE_SHADE_G 48
+#endif
+#ifndef RT_VOTE_LEAF_G
+#define RT_VOTE_LEAF_G 16
+#endif
+#ifndef RT_NODE_KEEP_G
+#define RT_NODE_KEEP_G 8
+#endif
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 4 /* spheres-only kernel: 105 VGPRs fit 4 waves per SIMD */
 #endif
@@ -122,7 +132,9 @@ __global__ __launch_bounds__(RT_BLOCK, (GENERAL ? RT_WAVES_PER_EU_GENERAL : RT_W
         if ((mS | mL | mN) == 0ull) break; // every lane is dead
         const int nS = __popcll(mS), nL = __popcll(mL), nN = __popcll(mN);
 
-        if (nS >= RT_VOTE_SHADE || (nN == 0 && nL == 0)) {
+        constexpr int kVoteShade = GENERAL ? RT_VOTE_SHADE_G : RT_VOTE_SHADE, kVoteLeaf = GENERAL ? RT_VOTE_LEAF_G : RT_VOTE_LEAF,
+                      kNodeKeep = GENERAL ? RT_NODE_KEEP_G : RT_NODE_KEEP;
+        if (nS >= kVoteShade || (nN == 0 && nL == 0)) {
             // ---------------- shade block ----------------
             if (COUNT && counting_lane) {
                 ++c_sw;
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(RT_BLOCK, (GENERAL ? RT_WAVES_PER_EU_GENERAL : RT_W
             }
             RT_STAMP(t1);
             t_beg += t1 - t0;
-        } else if (nL >= RT_VOTE_LEAF || nN == 0) {
+        } else if (nL >= kVoteLeaf || nN == 0) {
             // ---------------- leaf block ----------------
             if (COUNT && counting_lane) {
                 ++c_lw;
@@ -228,7 +240,7 @@ __global__ __launch_bounds__(RT_BLOCK, (GENERAL ? RT_WAVES_PER_EU_GENERAL : RT_W
                     if (COUNT) ++c_nodes;
                     rtl::trav_node_step(nodes, tv, st);
                 }
-                if (n < RT_NODE_KEEP) break;
+                if (n < kNodeKeep) break;
             }
             RT_STAMP(t1);
             t_n += t1 - t0;
