@@ -115,7 +115,7 @@ __global__ __launch_bounds__(RT_BLOCK, (GENERAL ? RT_WAVES_PER_EU_GENERAL : RT_W
     uint32_t slot = 0; // index of this lane's sample in L.samples
 
     // wave-uniform job state
-    uint32_t job_next = 0, job_left = 0, job_slot0 = 0, job_x0 = 0, job_y0 = 0, job_s_first = 0;
+    uint32_t job_next = 0, job_left = 0, job_slot0 = 0, job_x0 = 0, job_y0 = 0, job_s_first = 0, job_nspp = 1;
     bool queue_empty = false;
 
     unsigned long long c_nodes = 0, c_prims = 0, c_segs = 0, c_draws = 0, c_samples = 0;
@@ -185,6 +185,7 @@ __global__ __launch_bounds__(RT_BLOCK, (GENERAL ? RT_WAVES_PER_EU_GENERAL : RT_W
                     job_s_first = sub * (uint32_t)L.job_spp;
                     const uint32_t nspp = min((uint32_t)L.job_spp, (uint32_t)L.s_count - job_s_first);
                     job_left = nspp * RT_TILE_PIXELS;
+                    job_nspp = nspp;
                     job_next = 0u;
                     job_slot0 = (k * (uint32_t)L.s_count + job_s_first) * RT_TILE_PIXELS;
                 }
@@ -192,11 +193,13 @@ __global__ __launch_bounds__(RT_BLOCK, (GENERAL ? RT_WAVES_PER_EU_GENERAL : RT_W
                 const uint32_t rank = lane_rank(m);
                 if (need && rank < take) {
                     const uint32_t n = job_next + rank;
-                    const uint32_t pix = n & 63u;
+                    // pixel-major order inside a job: consecutive n are consecutive samples of ONE pixel, so
+                    // lanes refilled together start with near-identical rays (+1 % over sample-major)
+                    const uint32_t pix = n / job_nspp, sj = n - pix * job_nspp;
                     const uint32_t x = job_x0 + (pix & 7u), y = job_y0 + (pix >> 3);
                     if (x < (uint32_t)L.width && y < (uint32_t)L.height) {
-                        slot = job_slot0 + n;
-                        rtl::start_sample<LENS>(L, x, y, (uint32_t)L.s0 + job_s_first + (n >> 6), &ps);
+                        slot = job_slot0 + sj * RT_TILE_PIXELS + pix;
+                        rtl::start_sample<LENS>(L, x, y, (uint32_t)L.s0 + job_s_first + sj, &ps);
                         has_path = true;
                         need = false;
                     }
