@@ -315,3 +315,15 @@ def test_bad_arguments_are_errors_not_crashes(rt, scenes, gpu_device):
         assert e.value.code == -1
     with pytest.raises(rt.RtError):
         sc.render(cam, 1 << 15, 1 << 15, 1 << 12, 5)  # >= 2^40 sample streams
+
+
+def test_algorithmic_counts_match_committed_fixture(rt, scenes, gpu_device):
+    """tests/golden/algo_counts_book_one_1200x800.json are the roofline denominators; the
+    kernel's counters are deterministic, so the same launch must reproduce them exactly."""
+    import json
+    from pathlib import Path
+    fx = json.load(open(Path(__file__).resolve().parent / "golden" / "algo_counts_book_one_1200x800.json"))
+    sc, cam = scenes.build_product(scenes.book_one(fx["scene_seed"], fx["width"] / fx["height"]), device=gpu_device)
+    _, c = sc.render(cam, fx["width"], fx["height"], fx["spp_measured"], fx["max_depth"], seed=fx["render_seed"], counters=True)
+    assert (c["samples"], c["segments"], c["nodes_visited"], c["prims_tested"]) == \
+        (fx["samples"], fx["segments"], fx["node_steps"], fx["prim_tests"])

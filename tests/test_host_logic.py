@@ -219,3 +219,14 @@ def test_scene_generators_are_seeded(scenes):
     cv = scenes.cover(1)
     heights = [cv.geometries[s[0]][2] for s in cv.sprites[:400]]
     assert all(1.0 <= hgt < 101.0 for hgt in heights)
+
+
+def test_reference_limits_of_this_build(rt):
+    """16-bit node references: more than 32767 hittable sprites is refused at commit, not mis-rendered."""
+    s = rt.Scene()
+    g = s.sphere(0.1)
+    for i in range(32768):
+        s.sprite(g, None, [1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0, float(i), 0.0, 0.0, 1.0])
+    with pytest.raises(rt.RtError) as e:
+        s.commit(-1)
+    assert e.value.code == -4
