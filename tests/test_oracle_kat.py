@@ -395,3 +395,21 @@ def test_recursive_and_iterative_forms_agree(oracle, scenes):
     assert np.abs(a - b).max() <= 4e-16 * max(1.0, a.max())
     # threads only deal rows: identical image for any thread count
     assert np.array_equal(a, o.render(48, 32, 4, 50, seed=1, iterative=False, nthreads=1))
+
+
+def test_unit53_bit_construction_is_exact(oracle, scenes):
+    """rt_u64_to_unit53 builds (x >> 11) * 2^-53 from bits; compare with the plain formula through the C code
+    (randomInUnitSphere's first component is unit53 * 2 - 1) on many streams, plus the corner patterns."""
+    out = np.zeros(3)
+    for seed in range(200):
+        oracle.LIB.orc_kat_random_in_unit_sphere(seed, 77, oracle.dp(out))
+        g = scenes.HostRng(seed, 77)
+        while True:
+            p = [(g.next_u64() >> 11) * 2.0 ** -53 * 2.0 - 1.0 for _ in range(3)]
+            if p[0] * p[0] + p[1] * p[1] + p[2] * p[2] < 1.0:
+                break
+        assert out.tolist() == p
+    for x in (0, 0x7FF, 0x800, 0xFFF, 0x1000, 0x1800, 2**64 - 1, 2**64 - 0x800, 2**63, 2**63 + 0x800):
+        hi = struct.unpack("<d", struct.pack("<Q", (x >> 12) | 0x3FF0000000000000))[0] - 1.0
+        lo = 2.0 ** -53 if (x & 0x800) else 0.0
+        assert hi + lo == (x >> 11) * 2.0 ** -53
