@@ -19,7 +19,7 @@
 //   of every lane dragging the other 63 through its own branch.  Lanes never idle
 //   at sample, pixel or tile boundaries; a wave retires only when the job queue
 //   is empty.  Scheduling never changes a result: each path consumes its own
-//   counter-based random stream and every sample is an independent value.
+//   random stream (include/rt_rng.h) and every sample is an independent value.
 //   The traversal stack lives in LDS, [depth][thread], conflict-free ds_read/write_b32.
 //
 // reduce_kernel -- pixel = (((s_0 + s_1) + s_2) + ...) / spp in sample order, the

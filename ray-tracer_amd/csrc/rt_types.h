@@ -40,8 +40,7 @@ enum RtMaterialKind : uint32_t {
 enum RtTextureKind : uint32_t { RT_TEX_SOLID = 0, RT_TEX_CHECKER = 1, RT_TEX_IMAGE = 2 };
 
 // BVH2 node, binary32 CULLING boxes of both children stored in the parent, planes
-// interleaved as (child0, child1) pairs so one packed-f32 instruction handles both
-// children.  Boxes are rounded outward and padded (see rt_host.cpp): they only ever
+// interleaved as (child0, child1) pairs.  Boxes are rounded outward and padded (see rt_host.cpp): they only ever
 // decide which f64 primitive tests are skipped, never a result.
 struct alignas(16) RtNode {
     float lo_x[2], lo_y[2], lo_z[2]; // [child]
