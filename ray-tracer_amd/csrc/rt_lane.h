@@ -563,7 +563,10 @@ RT_HD bool shade(const RtLaunch &L, const RtMaterial &M, const Rec &rec, V3 d_in
         }
     }
     V3 vn = normalized(v);
-    *d_out = norm ? vn : v;
+    // component-wise selects: a struct-valued ?: is lowered to a round trip through scratch memory
+    d_out->x = norm ? vn.x : v.x;
+    d_out->y = norm ? vn.y : v.y;
+    d_out->z = norm ? vn.z : v.z;
     return true;
 }
 
