@@ -368,6 +368,10 @@ KernelFn pick(unsigned features, bool lens, bool count, bool ldsnodes) {
 extern "C" int rt_launch_render(const RtLaunch *L, unsigned features, int lens, int count, int ldsnodes, int blocks,
                                 unsigned lds_bytes, void *stream) {
     KernelFn k = pick(features, lens != 0, count != 0, ldsnodes != 0);
+    if (lds_bytes > 48u * 1024u) { // dynamic LDS beyond the default limit must be requested explicitly
+        hipError_t ea = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (ea != hipSuccess) return (int)ea;
+    }
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(RT_BLOCK), lds_bytes, (hipStream_t)stream, *L);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

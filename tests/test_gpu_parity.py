@@ -327,3 +327,27 @@ def test_algorithmic_counts_match_committed_fixture(rt, scenes, gpu_device):
     _, c = sc.render(cam, fx["width"], fx["height"], fx["spp_measured"], fx["max_depth"], seed=fx["render_seed"], counters=True)
     assert (c["samples"], c["segments"], c["nodes_visited"], c["prims_tested"]) == \
         (fx["samples"], fx["segments"], fx["node_steps"], fx["prim_tests"])
+
+
+@pytest.mark.parametrize("n_side", [27, 36])
+def test_large_lds_footprints(rt, scenes, oracle, gpu_device, n_side):
+    """~730 spheres: node copy + stack > 64 KB of dynamic LDS per workgroup (needs the explicit attribute);
+    ~1300 spheres: the node array no longer fits next to the stack and stays in global memory."""
+    rng = np.random.default_rng(n_side)
+    d = scenes.SceneDesc()
+    g = d.geom("sphere", 0.3)
+    mats = [d.lambertian_rgb(rng.uniform(0.1, 0.9, 3)) for _ in range(5)] + [d.mat("metal", d.tex_solid((0.8, 0.8, 0.8)), 0.1),
+                                                                               d.mat("dielectric", 1.5)]
+    for i in range(n_side):
+        for j in range(n_side):
+            d.sprite(g, mats[int(rng.integers(len(mats)))], scenes.mat4_translation((i - n_side / 2 + rng.uniform(0, 0.3), 0.3,
+                                                                                      j - n_side / 2 + rng.uniform(0, 0.3))))
+    d.sprite(d.geom("sphere", 1000.0), d.lambertian_rgb((0.5, 0.5, 0.5)), scenes.mat4_translation((0.0, -1000.0, 0.0)))
+    d.sprite(d.geom("sphere", 3000.0), d.mat("diffuse_light", d.tex_solid((0.6, 0.7, 1.0))), None)
+    d.camera = ((20.0, 6.0, 8.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 0.5, 1.5, 20.0, 0.02)
+    sc, cam = scenes.build_product(d, device=gpu_device)
+    info = sc.info()
+    assert info["n_nodes"] == n_side * n_side - 1
+    img = sc.render(cam, 60, 40, 4, 50, seed=3)
+    ref = oracle.build_oracle(d).render(60, 40, 4, 50, seed=3, iterative=True, nthreads=8)
+    _close(img, ref, max_bad=1)
