@@ -351,3 +351,20 @@ def test_large_lds_footprints(rt, scenes, oracle, gpu_device, n_side):
     img = sc.render(cam, 60, 40, 4, 50, seed=3)
     ref = oracle.build_oracle(d).render(60, 40, 4, 50, seed=3, iterative=True, nthreads=8)
     _close(img, ref, max_bad=1)
+
+
+def test_statistical_seed_independence_and_convergence(rt, scenes, gpu_device):
+    """Two disjoint render seeds estimate the same image: their difference shrinks like 1/sqrt(spp), and
+    no pixel exceeds the brightest emitter times albedo <= 1 (book-one: sky (0.5, 0.7, 1.0))."""
+    W, H = 120, 80
+    d = scenes.book_one(1, W / H)
+    sc, cam = scenes.build_product(d, device=gpu_device)
+    err = {}
+    for spp in (16, 256):
+        a = sc.render(cam, W, H, spp, 100, seed=1)
+        b = sc.render(cam, W, H, spp, 100, seed=2)
+        assert a.max() <= 1.0 + 1e-12 and a.min() >= 0.0 and np.all(a[..., 0] <= a[..., 2] + 1e-12 + 1.0)
+        err[spp] = float(np.sqrt(np.mean((a - b) ** 2)))
+        assert abs(a.mean() - b.mean()) < 5 * err[spp] / np.sqrt(W * H)  # no seed-dependent bias in the image mean
+    ratio = err[16] / err[256]
+    assert 3.0 < ratio < 5.5, ratio  # sqrt(256 / 16) = 4
