@@ -155,6 +155,13 @@ typedef struct rt_counters {
  * this shard's pixels are written.  counters may be NULL. */
 int rt_render(rt_scene *, const rt_camera *, const rt_render_params *, double *out_rgb, rt_counters *counters);
 
+/* Progressive / resumable rendering (the reference has none: a render is all-or-nothing and a 16.6 Gsample
+ * image takes a while).  Renders samples s in [s_begin, s_end) of every pixel of this shard -- the streams are
+ * those of the full `params->spp` render -- and continues the raw per-pixel sums in `sums` ([y][x][3], y up)
+ * in sample order.  s_begin == 0 starts from zero; call with consecutive ranges; save `sums` + s_end to
+ * checkpoint.  After the last range divide by spp: the image is bit-identical to one rt_render call. */
+int rt_render_progressive(rt_scene *, const rt_camera *, const rt_render_params *, int s_begin, int s_end, double *sums);
+
 /* Device-resident variant for callers that own device memory and a stream
  * (plumbed as raw pointers; `stream` is a hipStream_t or NULL).
  * d_tiles_out receives this shard's tiles PACKED in ascending tile id:

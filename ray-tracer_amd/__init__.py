@@ -99,6 +99,7 @@ ABI = {
     "rt_scene_commit": (C.c_int, [_VP, C.c_int]),
     "rt_camera_perspective": (C.c_int, [C.POINTER(rt_camera), _DP, _DP, _DP, _D, _D, _D, _D]),
     "rt_render": (C.c_int, [_VP, C.POINTER(rt_camera), C.POINTER(rt_render_params), _DP, C.POINTER(rt_counters)]),
+    "rt_render_progressive": (C.c_int, [_VP, C.POINTER(rt_camera), C.POINTER(rt_render_params), C.c_int, C.c_int, _DP]),
     "rt_shard_tile_count": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "rt_render_tiles_device": (C.c_int, [_VP, C.POINTER(rt_camera), C.POINTER(rt_render_params), _VP, _VP, _VP]),
     "rt_unpack_tiles_device": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, _VP]),
@@ -281,6 +282,13 @@ class Scene:
         cnt = rt_counters() if counters else None
         _check(lib().rt_render(self._h, C.byref(cam.c), C.byref(p), _dp(out), C.byref(cnt) if counters else None))
         return (out, cnt.as_dict()) if counters else out
+
+    def render_progressive(self, cam: "Camera", width, height, spp, max_depth, seed, s_begin, s_end, sums: np.ndarray, shard=(0, 1)):
+        """Continue the raw per-pixel sums with samples [s_begin, s_end) of the spp-sample render (in place)."""
+        p = rt_render_params(width, height, spp, max_depth, seed, shard[0], shard[1], 0)
+        assert sums.dtype == np.float64 and sums.shape == (height, width, 3) and sums.flags.c_contiguous
+        _check(lib().rt_render_progressive(self._h, C.byref(cam.c), C.byref(p), s_begin, s_end, _dp(sums)))
+        return sums
 
     def render_tiles_device(self, cam: "Camera", width, height, spp, max_depth, seed, shard, d_out_ptr, d_counters_ptr=None,
                             stream_ptr=None, flags=0):

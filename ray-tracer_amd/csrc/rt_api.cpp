@@ -290,10 +290,13 @@ static size_t sample_workspace_cap() {
     return (size_t)32 << 30; // 32 GiB of the 288 GB
 }
 
-int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_render_params *p, void *d_tiles_out, void *d_counters,
-                           void *stream) {
+// Render samples [s_begin, s_end) of every owned pixel.  accumulate: the tile buffer already holds the
+// raw sums of samples [0, s_begin) and is continued in sample order; finalize: divide by spp at the end.
+static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_params *p, int s_begin, int s_end, bool accumulate,
+                        bool finalize, void *d_tiles_out, void *d_counters, void *stream) {
     if (int e = check_params(s, cam, p)) return e;
     if (!d_tiles_out) return fail(RT_ERR_INVALID, "null output buffer");
+    if (s_begin < 0 || s_end > p->spp || s_begin >= s_end) return fail(RT_ERR_INVALID, "bad sample range");
     HIP_TRY(hipSetDevice(s->device));
     const int n_owned = rt_shard_tile_count(p->width, p->height, p->shard_index, p->shard_count);
     if (n_owned < 0) return n_owned;
@@ -304,13 +307,14 @@ int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_render_pa
     if (n_owned == 0) return RT_OK;
     const size_t tile_doubles = (size_t)n_owned * RT_TILE_PIXELS * 3;
     if (p->max_depth == 0) {
-        // color(ray, world, 0) is black before anything is traced (src/render.rs:6-8)
-        HIP_TRY(hipMemsetAsync(d_tiles_out, 0, tile_doubles * sizeof(double), st));
+        // color(ray, world, 0) is black before anything is traced (src/render.rs:6-8): sums stay as they are
+        if (!accumulate) HIP_TRY(hipMemsetAsync(d_tiles_out, 0, tile_doubles * sizeof(double), st));
         return RT_OK;
     }
     // pass size: as many samples per pixel as the workspace cap allows (32-byte record per sample)
     const size_t bytes_per_spp = (size_t)n_owned * RT_TILE_PIXELS * 4 * sizeof(double);
-    int chunk = (int)std::min<size_t>((size_t)p->spp, std::max<size_t>(1, sample_workspace_cap() / bytes_per_spp));
+    const int n_spp = s_end - s_begin;
+    int chunk = (int)std::min<size_t>((size_t)n_spp, std::max<size_t>(1, sample_workspace_cap() / bytes_per_spp));
     // slot indices are 32-bit
     chunk = (int)std::min<size_t>((size_t)chunk, (size_t)0xFFFFFFFFu / ((size_t)n_owned * RT_TILE_PIXELS));
     if (chunk < 1) return fail(RT_ERR_INVALID, "image too large for one shard");
@@ -355,15 +359,15 @@ int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_render_pa
     }
     L.samples = (double *)s->d_samples;
     L.counters = count ? (RtCounters *)d_counters : nullptr;
-    const int n_pass = (p->spp + chunk - 1) / chunk;
+    const int n_pass = (n_spp + chunk - 1) / chunk;
     while ((int)s->events.size() < 2 * n_pass) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
         s->events.push_back(e);
     }
     for (int pass = 0; pass < n_pass; ++pass) {
-        L.s0 = pass * chunk;
-        L.s_count = std::min(chunk, p->spp - L.s0);
+        L.s0 = s_begin + pass * chunk;
+        L.s_count = std::min(chunk, s_end - L.s0);
         // job size: at most RT_JOB_SPP_MAX samples per pixel, smaller when the pass is small so that
         // every resident wave still draws >= ~32 jobs (end-of-launch tail <= ~3 %)
         {
@@ -385,10 +389,66 @@ int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_render_pa
         if (rc != 0) return hip_fail((hipError_t)rc, "render_kernel launch");
         HIP_TRY(hipEventRecord(s->events[(size_t)(2 * pass + 1)], st));
         s->events_used = 2 * (pass + 1);
-        rc = rt_launch_reduce(L.samples, (double *)d_tiles_out, n_owned, L.s_count, pass == 0, pass == n_pass - 1, p->spp, p->width,
+        rc = rt_launch_reduce(L.samples, (double *)d_tiles_out, n_owned, L.s_count, pass == 0 && !accumulate,
+                              pass == n_pass - 1 && finalize, p->spp, p->width,
                               p->height, p->shard_index, p->shard_count, stream);
         if (rc != 0) return hip_fail((hipError_t)rc, "reduce_kernel launch");
     }
+    return RT_OK;
+}
+
+int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_render_params *p, void *d_tiles_out, void *d_counters,
+                           void *stream) {
+    if (!p) return fail(RT_ERR_INVALID, "null argument");
+    return render_range(s, cam, p, 0, p->spp, false, true, d_tiles_out, d_counters, stream);
+}
+
+int rt_render_progressive(rt_scene *s, const rt_camera *cam, const rt_render_params *p, int s_begin, int s_end, double *sums) {
+    if (int e = check_params(s, cam, p)) return e;
+    if (!sums) return fail(RT_ERR_INVALID, "null sums buffer");
+    if (s_begin < 0 || s_end > p->spp || s_begin >= s_end) return fail(RT_ERR_INVALID, "bad sample range");
+    std::lock_guard<std::mutex> render_lock(s->render_mu);
+    HIP_TRY(hipSetDevice(s->device));
+    const int n_owned = rt_shard_tile_count(p->width, p->height, p->shard_index, p->shard_count);
+    if (n_owned <= 0) return n_owned;
+    const size_t n_doubles = (size_t)n_owned * RT_TILE_PIXELS * 3;
+    std::vector<double> host(n_doubles, 0.0);
+    const int tx_n = tiles_x_of(p->width);
+    auto each_pixel = [&](auto &&f) { // f(index into host, index into sums)
+        for (int k = 0; k < n_owned; ++k) {
+            const int tile = p->shard_index + k * p->shard_count;
+            const int tx = tile % tx_n, ty = tile / tx_n;
+            for (int lane = 0; lane < RT_TILE_PIXELS; ++lane) {
+                const int x = tx * RT_TILE + (lane & 7), y = ty * RT_TILE + (lane >> 3);
+                if (x >= p->width || y >= p->height) continue;
+                f(((size_t)k * RT_TILE_PIXELS + (size_t)lane) * 3, ((size_t)y * (size_t)p->width + (size_t)x) * 3);
+            }
+        }
+    };
+    const bool accumulate = s_begin > 0;
+    if (accumulate) each_pixel([&](size_t h, size_t g) {
+        host[h] = sums[g];
+        host[h + 1] = sums[g + 1];
+        host[h + 2] = sums[g + 2];
+    });
+    double *d_out = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_out, n_doubles * sizeof(double)));
+    int rc = RT_OK;
+    hipError_t e = hipMemcpy(d_out, host.data(), n_doubles * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = hip_fail(e, "sums upload");
+    rt_render_params q = *p;
+    q.flags &= ~RT_FLAG_COUNTERS;
+    if (rc == RT_OK) rc = render_range(s, cam, &q, s_begin, s_end, accumulate, false, d_out, nullptr, nullptr);
+    if (rc == RT_OK && (e = hipStreamSynchronize(nullptr)) != hipSuccess) rc = hip_fail(e, "render_kernel execution");
+    if (rc == RT_OK && (e = hipMemcpy(host.data(), d_out, n_doubles * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess)
+        rc = hip_fail(e, "sums download");
+    (void)hipFree(d_out);
+    if (rc != RT_OK) return rc;
+    each_pixel([&](size_t h, size_t g) {
+        sums[g] = host[h];
+        sums[g + 1] = host[h + 1];
+        sums[g + 2] = host[h + 2];
+    });
     return RT_OK;
 }
 

@@ -9,6 +9,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <typeinfo>
@@ -21,6 +22,8 @@ struct Options {
     int width, height, spp, depth = 100, device = 0;
     uint64_t seed = 1, scene_seed = 1;
     std::string out = "-";
+    std::string checkpoint; // raw sums + progress, rewritten after every pass; an existing matching file is resumed
+    int passes = 1;
     bool describe = false;
 };
 
@@ -46,10 +49,12 @@ inline Options parse(int argc, char **argv, int w, int h, int spp) {
         else if (a == "--seed") o.seed = std::strtoull(next(), nullptr, 10);
         else if (a == "--scene-seed") o.scene_seed = std::strtoull(next(), nullptr, 10);
         else if (a == "--out") o.out = next();
+        else if (a == "--passes") o.passes = std::atoi(next());
+        else if (a == "--checkpoint") o.checkpoint = next();
         else if (a == "--describe") o.describe = true;
         else {
             std::fprintf(stderr, "usage: %s [--width W] [--height H] [--spp N] [--depth D] [--seed S] [--scene-seed S] "
-                                 "[--device I] [--out file.ppm|-] [--describe]\n", argv[0]);
+                                 "[--device I] [--out file.ppm|-] [--passes N] [--checkpoint file] [--describe]\n", argv[0]);
             std::exit(2);
         }
     }
@@ -132,7 +137,51 @@ inline int run(const Options &o, const std::vector<SpritePtr> &sprites, const Pe
         std::fprintf(stderr, "empty scene\n");
         return 1;
     }
-    std::vector<Vec3> buffer = render(*world, camera, o.width, o.height, o.spp, o.depth, o.seed);
+    std::vector<Vec3> buffer;
+    if (o.passes <= 1 && o.checkpoint.empty()) {
+        buffer = render(*world, camera, o.width, o.height, o.spp, o.depth, o.seed);
+    } else {
+        // progressive: the reference's only progress report is main.rs printing finished rows to stderr
+        // (examples/main.rs:123-125) and it cannot resume; here every pass can be checkpointed
+        struct Header {
+            uint64_t magic, width, height, spp, depth, seed, s_done;
+        } h{0x3150545252ull, (uint64_t)o.width, (uint64_t)o.height, (uint64_t)o.spp, (uint64_t)o.depth, o.seed, 0};
+        std::vector<double> sums((size_t)o.width * o.height * 3, 0.0);
+        int done = 0;
+        if (!o.checkpoint.empty()) {
+            if (FILE *f = std::fopen(o.checkpoint.c_str(), "rb")) {
+                Header g{};
+                if (std::fread(&g, sizeof g, 1, f) == 1 && g.magic == h.magic && g.width == h.width && g.height == h.height &&
+                    g.spp == h.spp && g.depth == h.depth && g.seed == h.seed && g.s_done <= h.spp &&
+                    std::fread(sums.data(), sizeof(double), sums.size(), f) == sums.size()) {
+                    done = (int)g.s_done;
+                    std::fprintf(stderr, "resuming %s at %d / %d spp\n", o.checkpoint.c_str(), done, o.spp);
+                } else {
+                    std::fill(sums.begin(), sums.end(), 0.0);
+                }
+                std::fclose(f);
+            }
+        }
+        const int passes = o.passes < 1 ? 1 : o.passes;
+        const int per = (o.spp + passes - 1) / passes;
+        while (done < o.spp) {
+            const int end = done + per < o.spp ? done + per : o.spp;
+            render_progressive(*world, camera, o.width, o.height, o.spp, o.depth, o.seed, done, end, sums);
+            done = end;
+            std::fprintf(stderr, "%d / %d spp\n", done, o.spp);
+            if (!o.checkpoint.empty()) {
+                if (FILE *f = std::fopen(o.checkpoint.c_str(), "wb")) {
+                    h.s_done = (uint64_t)done;
+                    std::fwrite(&h, sizeof h, 1, f);
+                    std::fwrite(sums.data(), sizeof(double), sums.size(), f);
+                    std::fclose(f);
+                }
+            }
+        }
+        buffer.resize((size_t)o.width * o.height);
+        const double n = (double)o.spp;
+        for (size_t i = 0; i < buffer.size(); ++i) buffer[i] = Vec3(sums[i * 3] / n, sums[i * 3 + 1] / n, sums[i * 3 + 2] / n);
+    }
     write_ppm(o.out == "-" ? "/dev/stdout" : o.out, buffer, o.width, o.height); // P3 text like println! in the reference
     return 0;
 }

@@ -278,6 +278,15 @@ inline std::vector<Vec3> render(const BoundingVolumeHierarchyNode &world, const 
     for (size_t i = 0; i < out.size(); ++i) out[i] = Vec3(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]);
     return out;
 }
+// Progressive form of render(): continues the raw per-pixel sums (width*height*3 doubles, y up) with samples
+// [s_begin, s_end) of the subPixelSampleCount-sample render; divide by subPixelSampleCount after the last
+// range.  Bit-identical to one render() call (rt_render_progressive).
+inline void render_progressive(const BoundingVolumeHierarchyNode &world, const PerspectiveCamera &camera, int width, int height,
+                               int subPixelSampleCount, int maxDepth, uint64_t seed, int s_begin, int s_end, std::vector<double> &sums) {
+    sums.resize((size_t)width * height * 3);
+    rt_render_params p{width, height, subPixelSampleCount, maxDepth, seed, 0, 1, 0u};
+    check(rt_render_progressive(world.raw(), &camera.c, &p, s_begin, s_end, sums.data()));
+}
 inline void write_ppm(const std::string &path, const std::vector<Vec3> &buffer, int width, int height) {
     std::vector<double> rgb(buffer.size() * 3);
     for (size_t i = 0; i < buffer.size(); ++i) {

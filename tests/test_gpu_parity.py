@@ -368,3 +368,26 @@ def test_statistical_seed_independence_and_convergence(rt, scenes, gpu_device):
         assert abs(a.mean() - b.mean()) < 5 * err[spp] / np.sqrt(W * H)  # no seed-dependent bias in the image mean
     ratio = err[16] / err[256]
     assert 3.0 < ratio < 5.5, ratio  # sqrt(256 / 16) = 4
+
+
+def test_progressive_render_is_bit_identical(rt, scenes, gpu_device):
+    """rt_render_progressive over consecutive sample ranges (with a 'checkpoint' through a file) equals one render."""
+    import io
+    W, H, spp = 72, 48, 20
+    d = scenes.book_one(1, W / H)
+    sc, cam = scenes.build_product(d, device=gpu_device)
+    whole = sc.render(cam, W, H, spp, 50, seed=4)
+    sums = np.zeros((H, W, 3))
+    sc.render_progressive(cam, W, H, spp, 50, 4, 0, 7, sums)
+    buf = io.BytesIO()
+    np.save(buf, sums)  # checkpoint ...
+    buf.seek(0)
+    sums = np.load(buf)  # ... and resume, on a freshly committed scene
+    sc2, cam2 = scenes.build_product(d, device=gpu_device)
+    sc2.render_progressive(cam2, W, H, spp, 50, 4, 7, 8, sums)
+    sc2.render_progressive(cam2, W, H, spp, 50, 4, 8, 20, sums)
+    assert np.array_equal(sums / spp, whole)
+    with pytest.raises(rt.RtError):
+        sc2.render_progressive(cam2, W, H, spp, 50, 4, 5, 5, sums)
+    with pytest.raises(rt.RtError):
+        sc2.render_progressive(cam2, W, H, spp, 50, 4, 0, 21, sums)
