@@ -110,6 +110,7 @@ __global__ __launch_bounds__(RT_BLOCK, (GENERAL ? RT_WAVES_PER_EU_GENERAL : RT_W
     tv.cur = RT_CUR_DONE;
     tv.sp = 0;
     tv.best_prim = 0xFFFFFFFFu;
+    tv.best_sub = 0u;
     tv.best_t = 0.0;
     bool has_path = false;
     uint32_t slot = 0; // index of this lane's sample in L.samples

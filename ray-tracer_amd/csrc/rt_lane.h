@@ -65,6 +65,7 @@ struct Rec { // HitRecord, src/ray.rs:36-43 (material lives on the prim)
     double t;
     V3 p, n;
     double u, v;
+    uint32_t sub; // which face of a cube produced the hit (lets the shade step rebuild only that face)
 };
 
 // ---- per-sample random numbers: include/rt_rng.h ----
@@ -233,9 +234,12 @@ struct SegCtx { // what a primitive test may need besides the ray
 
 // Intersect primitive `pi` with the world ray; on a hit fill the world-space record.
 // RECORD = false: only r->t is meaningful (traversal); true: full record (shading).
+// only_face: RT_ALL_FACES, or the one cube face to evaluate (the winner found during traversal).
+#define RT_ALL_FACES 0xFFFFFFFFu
 template <bool GENERAL, bool MEDIUM, bool UV, bool RECORD>
-RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx &sc, Rec *r) {
+RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx &sc, Rec *r, uint32_t only_face = RT_ALL_FACES) {
     const RtPrimGeo &G = L.prim_geo[pi];
+    r->sub = 0u;
     uint32_t kind = (uint32_t)RT_PRIM_SPHERE_T;
     if (GENERAL || MEDIUM) kind = L.prim_meta[pi].kind;
     ++sc.prims_tested;
@@ -280,7 +284,8 @@ RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx
             // nearest face, strict <, first face wins ties; the boxes only filter
             const uint32_t first = P.aux, count = (uint32_t)G.g[0];
             double best = RTL_INF;
-            for (uint32_t k = 0; k < count; ++k) {
+            const uint32_t k0 = only_face == RT_ALL_FACES ? 0u : only_face, k1 = only_face == RT_ALL_FACES ? count : only_face + 1u;
+            for (uint32_t k = k0; k < k1; ++k) {
                 const RtPrimGeo &CG = L.prim_geo[first + k];
                 const RtXform &CX = L.xforms[L.prim_meta[first + k].xform];
                 V3 co = xf_point(CX.inv, lo);
@@ -291,6 +296,7 @@ RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx
                     best = cr.t;
                     if (RECORD) to_world(CX, &cr); // TransformedGeometry::hit, src/geometry.rs:228-236
                     *r = cr;
+                    r->sub = k;
                     ok = true;
                 }
             }
@@ -317,6 +323,7 @@ struct Trav {
     int32_t sp;          // stack pointer (entries live in the Stack policy object)
     double best_t;
     uint32_t best_prim;
+    uint32_t best_sub;   // winning cube face (general scenes)
     float best32;        // best_t rounded up to binary32
     float idx, idy, idz; // 1 / d
     float nx, ny, nz;    // -(o/d + pad): entry planes,  t = plane * id + n
@@ -388,6 +395,7 @@ RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack
     tv.fz = -(qz - ez);
     tv.best_t = RTL_INF;
     tv.best_prim = 0xFFFFFFFFu;
+    tv.best_sub = 0u;
     const double a = dot(d, d);
     for (int32_t pi = 0; pi < L.n_hoisted; ++pi) {
         Rec r;
@@ -395,6 +403,7 @@ RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack
             if (r.t < tv.best_t) { // ascending prim id: ties keep the lower id
                 tv.best_t = r.t;
                 tv.best_prim = (uint32_t)pi;
+                if (GENERAL) tv.best_sub = r.sub;
             }
         }
     }
@@ -447,6 +456,7 @@ RT_HD void trav_leaf_step(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, S
         if (r.t < tv.best_t || (r.t == tv.best_t && pi < tv.best_prim)) {
             tv.best_t = r.t;
             tv.best_prim = pi;
+            if (GENERAL) tv.best_sub = r.sub;
             tv.best32 = up32(r.t);
         }
     }
@@ -638,7 +648,8 @@ RT_HD bool finish_segment(const RtLaunch &L, PathState *ps, const Trav &tv, V3 *
         sc.segment = (uint32_t)ps->k;
         sc.draws = 0;
         sc.prims_tested = 0;
-        prim_hit<GENERAL, MEDIUM, UV, true>(L, prim, ps->o, ps->d, dot(ps->d, ps->d), sc, &rec);
+        // rebuild the record of the winner; for a cube only its winning face (same arithmetic, same t)
+        prim_hit<GENERAL, MEDIUM, UV, true>(L, prim, ps->o, ps->d, dot(ps->d, ps->d), sc, &rec, tv.best_sub);
     } else {
         const RtPrimGeo &G = L.prim_geo[prim];
         V3 c = mk(G.g[0], G.g[1], G.g[2]);
