@@ -413,3 +413,19 @@ def test_unit53_bit_construction_is_exact(oracle, scenes):
         hi = struct.unpack("<d", struct.pack("<Q", (x >> 12) | 0x3FF0000000000000))[0] - 1.0
         lo = 2.0 ** -53 if (x & 0x800) else 0.0
         assert hi + lo == (x >> 11) * 2.0 ** -53
+
+
+def test_dielectric_and_mirror_furnace(oracle, scenes):
+    """Energy conservation of the specular materials inside a uniform white light:
+    a glass sphere neither absorbs nor emits (attenuation (1,1,1), src/material.rs:148) -> every path that
+    ends on the light carries exactly 1.0; a perfect mirror (fuzz 0) carries albedo^bounces."""
+    for mat, expect_lo, expect_hi in (("dielectric", 1.0, 1.0), ("metal", 0.8, 0.8)):
+        d = scenes.SceneDesc()
+        m = d.mat("dielectric", 1.5) if mat == "dielectric" else d.mat("metal", d.tex_solid((0.8, 0.8, 0.8)), 0.0)
+        d.sprite(d.geom("sphere", 1.0), m, scenes.mat4_translation((0.0, 0.0, 5.0)))
+        d.sprite(d.geom("sphere", 100.0), d.mat("diffuse_light", d.tex_solid((1.0, 1.0, 1.0))), None)
+        d.camera = ((0.0, 0.0, 0.0), (0.0, 0.0, 5.0), (0.0, 1.0, 0.0), 0.3, 1.0, 1.0, 0.0)
+        img = oracle.build_oracle(d).render(9, 9, 32, 100, seed=3)
+        centre = img[4, 4]
+        assert np.all(centre >= expect_lo - 1e-12) and np.all(centre <= expect_hi + 1e-12), (mat, centre)
+        assert np.array_equal(img[0, 0], [1.0, 1.0, 1.0])  # corner pixel sees the light directly
