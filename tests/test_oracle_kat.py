@@ -424,7 +424,9 @@ def test_dielectric_and_mirror_furnace(oracle, scenes):
         m = d.mat("dielectric", 1.5) if mat == "dielectric" else d.mat("metal", d.tex_solid((0.8, 0.8, 0.8)), 0.0)
         d.sprite(d.geom("sphere", 1.0), m, scenes.mat4_translation((0.0, 0.0, 5.0)))
         d.sprite(d.geom("sphere", 100.0), d.mat("diffuse_light", d.tex_solid((1.0, 1.0, 1.0))), None)
-        d.camera = ((0.0, 0.0, 0.0), (0.0, 0.0, 5.0), (0.0, 1.0, 0.0), 0.3, 1.0, 1.0, 0.0)
+        # fov 1.0 rad: the sphere (half-angle atan(1/5) = 0.197 rad) fills the centre pixel (+-0.06 rad) and the
+        # corner pixel (0.66 rad off axis) misses it
+        d.camera = ((0.0, 0.0, 0.0), (0.0, 0.0, 5.0), (0.0, 1.0, 0.0), 1.0, 1.0, 1.0, 0.0)
         img = oracle.build_oracle(d).render(9, 9, 32, 100, seed=3)
         centre = img[4, 4]
         assert np.all(centre >= expect_lo - 1e-12) and np.all(centre <= expect_hi + 1e-12), (mat, centre)
