@@ -391,3 +391,21 @@ def test_progressive_render_is_bit_identical(rt, scenes, gpu_device):
         sc2.render_progressive(cam2, W, H, spp, 50, 4, 5, 5, sums)
     with pytest.raises(rt.RtError):
         sc2.render_progressive(cam2, W, H, spp, 50, 4, 0, 21, sums)
+
+
+@pytest.mark.parametrize("mat", ["dielectric", "metal"])
+def test_specular_furnace_matches_oracle(rt, scenes, oracle, gpu_device, mat):
+    """A glass / mirror sphere inside a uniform white light (the CPU KAT of the same name): the device must give
+    the analytic answer too -- 1.0 through glass, albedo off a fuzz-0 mirror -- and match the oracle."""
+    d = scenes.SceneDesc()
+    m = d.mat("dielectric", 1.5) if mat == "dielectric" else d.mat("metal", d.tex_solid((0.8, 0.8, 0.8)), 0.0)
+    d.sprite(d.geom("sphere", 1.0), m, scenes.mat4_translation((0.0, 0.0, 5.0)))
+    d.sprite(d.geom("sphere", 100.0), d.mat("diffuse_light", d.tex_solid((1.0, 1.0, 1.0))), None)
+    d.camera = ((0.0, 0.0, 0.0), (0.0, 0.0, 5.0), (0.0, 1.0, 0.0), 1.0, 1.0, 1.0, 0.0)
+    sc, cam = scenes.build_product(d, device=gpu_device)
+    img = sc.render(cam, 9, 9, 32, 100, seed=3)
+    ref = oracle.build_oracle(d).render(9, 9, 32, 100, seed=3, iterative=True)
+    assert np.abs(img - ref).mean() <= MAE_BAR
+    want = 1.0 if mat == "dielectric" else 0.8
+    assert np.all(np.abs(img[4, 4] - want) <= 1e-12), img[4, 4]
+    assert np.array_equal(img[0, 0], [1.0, 1.0, 1.0])
