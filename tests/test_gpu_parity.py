@@ -329,10 +329,11 @@ def test_algorithmic_counts_match_committed_fixture(rt, scenes, gpu_device):
         (fx["samples"], fx["segments"], fx["node_steps"], fx["prim_tests"])
 
 
-@pytest.mark.parametrize("n_side", [27, 36])
+@pytest.mark.parametrize("n_side", [27, 36, 150])
 def test_large_lds_footprints(rt, scenes, oracle, gpu_device, n_side):
     """~730 spheres: node copy + stack > 64 KB of dynamic LDS per workgroup (needs the explicit attribute);
-    ~1300 spheres: the node array no longer fits next to the stack and stays in global memory."""
+    ~1300 spheres: the node array no longer fits next to the stack and stays in global memory;
+    22500 spheres: 1.4 MB of nodes in L2, a deep tree, near the 16-bit reference limit."""
     rng = np.random.default_rng(n_side)
     d = scenes.SceneDesc()
     g = d.geom("sphere", 0.3)
