@@ -149,6 +149,10 @@ typedef struct rt_counters {
     uint64_t node_wave, node_lane, leaf_wave, leaf_lane, shade_wave, shade_lane;
     /* shader-clock cycles spent in each block, summed over waves (diagnostic) */
     uint64_t node_cycles, leaf_cycles, shade_cycles, finish_cycles, refill_cycles, begin_cycles;
+    /* swap-at-shade kernels only (0 otherwise): shade-block executions in a class mode / in new-sample mode, paths
+     * parked in and pulled from the workgroup queues, queue locks found busy, paths scattered, and of those the
+     * ones scattered outside the chosen class (could not be parked) */
+    uint64_t swap_class_mode, swap_new_mode, swap_parked, swap_pulled, swap_lock_busy, swap_scattered, swap_off_class;
 } rt_counters;
 
 /* Render into host memory: out_rgb[(y*W + x)*3 + c].  With shard_count > 1 only

@@ -49,7 +49,8 @@ class rt_counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "segments", "nodes_visited", "prims_tested", "rng_draws",
                                             "node_wave", "node_lane", "leaf_wave", "leaf_lane", "shade_wave", "shade_lane",
                                             "node_cycles", "leaf_cycles", "shade_cycles", "finish_cycles", "refill_cycles",
-                                            "begin_cycles")]
+                                            "begin_cycles", "swap_class_mode", "swap_new_mode", "swap_parked", "swap_pulled",
+                                            "swap_lock_busy", "swap_scattered", "swap_off_class")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

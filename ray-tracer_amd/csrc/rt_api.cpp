@@ -25,6 +25,7 @@ extern "C" int rt_launch_render(const RtLaunch *L, unsigned features, int lens, 
 extern "C" int rt_launch_reduce(const double *samples, double *tiles, int n_owned_tiles, int s_count, int first_pass, int last_pass,
                                 int spp, int width, int height, int shard_index, int shard_count, void *stream);
 extern "C" int rt_kernel_block_size(void);
+extern "C" unsigned rt_swap_lds_bytes(void);
 extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int ldsnodes, unsigned lds_bytes, int *blocks_per_cu,
                                     int *n_cu);
 extern "C" int rt_launch_unpack(const double *gathered, int tiles_per_shard, int shard_count, int width, int height,
@@ -340,16 +341,22 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     const unsigned stack_bytes = (unsigned)L.stack_entries * block * 4u;
     const unsigned node_bytes = (unsigned)(s->flat.nodes.size() * sizeof(RtNode));
     const char *no_lds = std::getenv("RT_NO_LDS_NODES");
+    // swap-at-shade queues (rt_kernels.hip); RT_SWAP=0 selects the kernels without them (A/B runs)
+    const char *swap_env = std::getenv("RT_SWAP");
+    const int swap = !(swap_env && *swap_env == '0');
+    const unsigned swap_bytes = swap ? rt_swap_lds_bytes() : 0u;
     // keep 16 waves per CU resident: (1024 / block) workgroups, each with its own node copy
-    const int ldsnodes = node_bytes > 0 && (1024u / block) * (stack_bytes + node_bytes) <= 160u * 1024u && !(no_lds && *no_lds == '1');
-    const unsigned lds_bytes = stack_bytes + (ldsnodes ? node_bytes : 0u);
+    const int ldsnodes = node_bytes > 0 && (1024u / block) * (stack_bytes + node_bytes + swap_bytes) <= 160u * 1024u &&
+                         !(no_lds && *no_lds == '1');
+    const unsigned lds_bytes = stack_bytes + (ldsnodes ? node_bytes : 0u) + swap_bytes;
+    const int lds_mode = (ldsnodes ? 1 : 0) | (swap ? 2 : 0);
     int per_cu = 0, n_cu = 0, rc = 0;
-    const unsigned occ_key = feat | (lens ? 8u : 0u) | (count ? 16u : 0u) | (ldsnodes ? 32u : 0u);
+    const unsigned occ_key = feat | (lens ? 8u : 0u) | (count ? 16u : 0u) | ((unsigned)lds_mode << 5);
     if (s->occ_key == occ_key && s->occ_lds == lds_bytes) {
         per_cu = s->occ_per_cu;
         n_cu = s->occ_n_cu;
     } else {
-        rc = rt_persistent_blocks(feat, lens, count, ldsnodes, lds_bytes, &per_cu, &n_cu);
+        rc = rt_persistent_blocks(feat, lens, count, lds_mode, lds_bytes, &per_cu, &n_cu);
         if (rc != 0) return hip_fail((hipError_t)rc, "occupancy query");
         if (per_cu < 1) per_cu = 1;
         s->occ_key = occ_key;
@@ -385,7 +392,7 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
         const int blocks = (int)std::min<long long>((long long)per_cu * n_cu, want > 0 ? want : 1);
         HIP_TRY(hipMemsetAsync(s->d_job_counter, 0, sizeof(unsigned int), st));
         HIP_TRY(hipEventRecord(s->events[(size_t)(2 * pass)], st));
-        rc = rt_launch_render(&L, feat, lens, count, ldsnodes, blocks, lds_bytes, stream);
+        rc = rt_launch_render(&L, feat, lens, count, lds_mode, blocks, lds_bytes, stream);
         if (rc != 0) return hip_fail((hipError_t)rc, "render_kernel launch");
         HIP_TRY(hipEventRecord(s->events[(size_t)(2 * pass + 1)], st));
         s->events_used = 2 * (pass + 1);
@@ -523,6 +530,13 @@ int rt_render(rt_scene *s, const rt_camera *cam, const rt_render_params *p, doub
             counters->finish_cycles = c.finish_cycles;
             counters->refill_cycles = c.refill_cycles;
             counters->begin_cycles = c.begin_cycles;
+            counters->swap_class_mode = c.swap_class_mode;
+            counters->swap_new_mode = c.swap_new_mode;
+            counters->swap_parked = c.swap_parked;
+            counters->swap_pulled = c.swap_pulled;
+            counters->swap_lock_busy = c.swap_lock_busy;
+            counters->swap_scattered = c.swap_scattered;
+            counters->swap_off_class = c.swap_off_class;
         }
     }
     (void)hipFree(d_out);

@@ -66,6 +66,39 @@
 #define RT_WAVES_PER_EU_GENERAL 2 /* general kernel (matrices, cubes, media, textures) needs the registers */
 #endif
 
+// iterations of the unit-ball rejection sampler per shade block (0 = run it to the end, like the reference's loop);
+// see rtl::random_in_unit_sphere_bounded
+#ifndef RT_BALL_ITERS
+#define RT_BALL_ITERS 0
+#endif
+
+// ---- swap-at-shade (SWAP kernels): per-workgroup queues of finished segments, one per scattering material class.
+// A wave that votes for the shade block parks the lanes of the other classes in LDS and pulls parked paths of ONE
+// class into its free lanes, so Material::scatter runs on (nearly) homogeneous lanes; new samples are started in
+// bulk the same way ("new" mode).  Nothing ever waits: a busy queue lock or a full queue just means the lane is
+// shaded in place.  Which lane or wave finishes a path cannot change its result (per-sample streams and records).
+#ifndef RT_SWAP_CAP
+#define RT_SWAP_CAP 64 /* entries per class queue */
+#endif
+#ifndef RT_SWAP_MODE_MIN
+#define RT_SWAP_MODE_MIN 56 /* a class needs this many lanes (own + parked) to be chosen over starting new samples */
+#endif
+#ifndef RT_SWAP_REFILL_MIN
+#define RT_SWAP_REFILL_MIN 65 /* empty lanes that force a refill even in a class mode */
+#endif
+#ifndef RT_SWAP_POLICY
+#define RT_SWAP_POLICY 0 /* 0: the class with most lanes (own + parked); 1: the eligible class with the fullest queue */
+#endif
+#ifndef RT_SWAP_LOCK_TRIES
+#define RT_SWAP_LOCK_TRIES 8
+#endif
+#define RT_SWAP_CLASSES 3  /* lambertian, metal, dielectric (RT_MAT_* values 0..2) */
+#define RT_SWAP_F64 14     /* o, d, T (9), s0, s1, best_t, draws, base */
+#define RT_SWAP_F32 4      /* k, best_prim, slot, best_sub */
+#define RT_SWAP_HDR_BYTES 32u
+#define RT_SWAP_CLASS_BYTES ((unsigned)((RT_SWAP_F64 * 8 + RT_SWAP_F32 * 4) * RT_SWAP_CAP))
+#define RT_SWAP_LDS_BYTES (RT_SWAP_HDR_BYTES + RT_SWAP_CLASSES * RT_SWAP_CLASS_BYTES)
+
 namespace {
 
 struct LdsStack {
@@ -90,20 +123,26 @@ __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__bui
 // in ~1/4 of an L2 hit.
 extern __shared__ __attribute__((aligned(16))) unsigned char rt_lds[];
 
-template <bool GENERAL, bool MEDIUM, bool TEXTURED, bool LENS, bool COUNT, bool LDSNODES>
+template <bool GENERAL, bool MEDIUM, bool TEXTURED, bool LENS, bool COUNT, bool LDSNODES, bool SWAP>
 __global__ __launch_bounds__(RT_BLOCK, (GENERAL ? RT_WAVES_PER_EU_GENERAL : RT_WAVES_PER_EU)) void render_kernel(const RtLaunch L) {
     uint32_t *stack_mem = reinterpret_cast<uint32_t *>(rt_lds);
     LdsStack st;
     st.base = stack_mem + threadIdx.x;
     const RtNode *nodes = L.nodes;
+    const unsigned node_lds_bytes = LDSNODES ? (unsigned)L.n_nodes * (unsigned)sizeof(RtNode) : 0u;
+    // swap queues: header {count[3], pad, lock[3], pad}, then per class RT_SWAP_F64 arrays of CAP doubles and
+    // RT_SWAP_F32 arrays of CAP words (field-major: consecutive entries are consecutive addresses)
+    unsigned char *swap_mem = rt_lds + (size_t)L.stack_entries * RT_BLOCK * sizeof(uint32_t) + node_lds_bytes;
+    uint32_t *swap_hdr = reinterpret_cast<uint32_t *>(swap_mem);
+    if (SWAP && threadIdx.x < RT_SWAP_HDR_BYTES / 4u) swap_hdr[threadIdx.x] = 0u;
     if (LDSNODES) {
         uint4 *dst = reinterpret_cast<uint4 *>(rt_lds + (size_t)L.stack_entries * RT_BLOCK * sizeof(uint32_t));
         const uint4 *src = reinterpret_cast<const uint4 *>(L.nodes);
         const int n16 = L.n_nodes * (int)(sizeof(RtNode) / 16);
         for (int i = (int)threadIdx.x; i < n16; i += RT_BLOCK) dst[i] = src[i];
-        __syncthreads();
         nodes = reinterpret_cast<const RtNode *>(dst);
     }
+    if (LDSNODES || SWAP) __syncthreads();
 
     rtl::PathState ps;
     rtl::Trav tv;
@@ -122,6 +161,7 @@ __global__ __launch_bounds__(RT_BLOCK, (GENERAL ? RT_WAVES_PER_EU_GENERAL : RT_W
     unsigned long long c_nodes = 0, c_prims = 0, c_segs = 0, c_draws = 0, c_samples = 0;
     unsigned long long c_nw = 0, c_nl = 0, c_lw = 0, c_ll = 0, c_sw = 0, c_sl = 0;
     unsigned long long t_n = 0, t_l = 0, t_s = 0, t_fin = 0, t_ref = 0, t_beg = 0, t0 = 0, t1 = 0;
+    unsigned long long w_class = 0, w_new = 0, w_park = 0, w_pull = 0, w_busy = 0, w_scat = 0, w_off = 0; // swap diagnostics
 #define RT_STAMP(v) do { if (COUNT) v = __builtin_amdgcn_s_memtime(); } while (0)
     const bool counting_lane = COUNT && (threadIdx.x & 63) == 0;
 
@@ -130,7 +170,14 @@ __global__ __launch_bounds__(RT_BLOCK, (GENERAL ? RT_WAVES_PER_EU_GENERAL : RT_W
         const bool is_leaf = (tv.cur & (RT_REF_LEAF | RT_CUR_DONE | RT_CUR_DEAD)) == RT_REF_LEAF;
         const bool is_node = tv.cur < RT_REF_LEAF;
         const unsigned long long mS = __ballot(is_done), mL = __ballot(is_leaf), mN = __ballot(is_node);
-        if ((mS | mL | mN) == 0ull) break; // every lane is dead
+        if ((mS | mL | mN) == 0ull) { // every lane is dead
+            if (!SWAP) break;
+            // ... but paths may still be parked in the workgroup's queues: the shade block below pulls them
+            const uint32_t parked = __hip_atomic_load(&swap_hdr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) |
+                                    __hip_atomic_load(&swap_hdr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) |
+                                    __hip_atomic_load(&swap_hdr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (parked == 0u) break;
+        }
         const int nS = __popcll(mS), nL = __popcll(mL), nN = __popcll(mN);
 
         constexpr int kVoteShade = GENERAL ? RT_VOTE_SHADE_G : RT_VOTE_SHADE, kVoteLeaf = GENERAL ? RT_VOTE_LEAF_G : RT_VOTE_LEAF,
@@ -143,11 +190,212 @@ __global__ __launch_bounds__(RT_BLOCK, (GENERAL ? RT_WAVES_PER_EU_GENERAL : RT_W
             }
             RT_STAMP(t0);
             bool need = false;
-            if (is_done) {
-                if (has_path) {
-                    if (COUNT) ++c_segs;
+            bool pending = false;  // the ball sampler hit its bound: the lane stays DONE and is shaded again
+            bool part = is_done;   // lanes this block works for
+            bool do_refill = true;
+            if constexpr (SWAP) {
+                constexpr uint32_t kInPlace = 3u, kEmpty = 4u, kNone = 7u;
+                const uint32_t lane = threadIdx.x & 63u;
+                // 1. classify.  Paths that end here without a hit record (black background, no material, a light
+                //    of one colour) are settled at once, so their lanes can take a parked path below.
+                uint32_t cls = kNone;
+                if ((is_done && !has_path) || tv.cur == RT_CUR_DEAD) cls = kEmpty;
+                if (is_done && has_path) {
+                    uint32_t mat = RT_NO_MATERIAL, kind = 0xFFu;
+                    if (tv.best_prim != 0xFFFFFFFFu) mat = L.prim_meta[tv.best_prim].material;
+                    if (mat != RT_NO_MATERIAL) kind = L.materials[mat].kind;
+                    if (kind < (uint32_t)RT_SWAP_CLASSES) {
+                        cls = kind;
+                    } else if (kind == RT_MAT_ISOTROPIC || (TEXTURED && kind == RT_MAT_DIFFUSE_LIGHT)) {
+                        cls = kInPlace;
+                    } else {
+                        rtl::V3 rad = rtl::mk(0.0, 0.0, 0.0);
+                        if (kind == RT_MAT_DIFFUSE_LIGHT) rad = ps.T * rtl::ld3(L.materials[mat].rgb); // finish_segment's T * emit
+                        double2 *o = reinterpret_cast<double2 *>(L.samples + (size_t)slot * 4);
+                        o[0] = make_double2(rad.x, rad.y);
+                        o[1] = make_double2(rad.z, 0.0);
+                        has_path = false;
+                        cls = kEmpty;
+                        if (COUNT) {
+                            ++c_segs;
+                            c_draws += ps.g.draws;
+                            ++c_samples;
+                        }
+                    }
+                }
+                // 2. mode: the class with the most lanes (own + parked), or "new samples" when no class fills the wave
+                const unsigned long long m0 = __ballot(cls == 0u), m1 = __ballot(cls == 1u), m2 = __ballot(cls == 2u);
+                const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2);
+                const uint32_t q0 = __hip_atomic_load(&swap_hdr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t q1 = __hip_atomic_load(&swap_hdr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t q2 = __hip_atomic_load(&swap_hdr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // a class is eligible when it can (nearly) fill the wave; among the eligible ones the fullest queue goes
+                // first, so the rare classes (metal, glass) are drained in whole waves instead of clogging their queue
+                const uint32_t t0s = n0 + q0, t1s = n1 + q1, t2s = n2 + q2;
+                uint32_t cstar = 0u, smax = t0s;
+                if (t1s > smax) {
+                    cstar = 1u;
+                    smax = t1s;
+                }
+                if (t2s > smax) {
+                    cstar = 2u;
+                    smax = t2s;
+                }
+                bool eligible = smax >= (uint32_t)RT_SWAP_MODE_MIN;
+                if (RT_SWAP_POLICY == 1) {
+                    eligible = false;
+                    uint32_t bestq = 0u;
+                    if (t0s >= (uint32_t)RT_SWAP_MODE_MIN) {
+                        eligible = true;
+                        cstar = 0u;
+                        bestq = q0;
+                    }
+                    if (t1s >= (uint32_t)RT_SWAP_MODE_MIN && (!eligible || q1 > bestq)) {
+                        eligible = true;
+                        cstar = 1u;
+                        bestq = q1;
+                    }
+                    if (t2s >= (uint32_t)RT_SWAP_MODE_MIN && (!eligible || q2 > bestq)) {
+                        eligible = true;
+                        cstar = 2u;
+                        bestq = q2;
+                    }
+                }
+                const bool mode_new = !queue_empty && !eligible;
+                const bool allow_push = !queue_empty; // once the job queue is dry the wave only drains
+                // 3. lanes 0..2 try the lock of "their" class (never wait: a busy queue is skipped this time)
+                uint32_t got = 0u, cnt = 0u, my_n = 0u;
+                if (lane < (uint32_t)RT_SWAP_CLASSES) {
+                    my_n = lane == 0u ? n0 : (lane == 1u ? n1 : n2);
+                    const uint32_t my_q = lane == 0u ? q0 : (lane == 1u ? q1 : q2);
+                    const bool push_c = allow_push && (mode_new || lane != cstar) && my_n > 0u && my_q < (uint32_t)RT_SWAP_CAP;
+                    const bool pull_c = !mode_new && lane == cstar && my_q > 0u;
+                    if (push_c || pull_c) {
+                        // bounded retry: a holder never waits for anything, so the lock frees within a few hundred cycles
+                        for (int attempt = 0; attempt < RT_SWAP_LOCK_TRIES && got == 0u; ++attempt) {
+                            uint32_t expected = 0u;
+                            if (__hip_atomic_compare_exchange_strong(&swap_hdr[4u + lane], &expected, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                                got = 1u;
+                                cnt = __hip_atomic_load(&swap_hdr[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            } else {
+                                __builtin_amdgcn_s_sleep(2);
+                            }
+                        }
+                        if (COUNT && got == 0u) ++w_busy;
+                    }
+                }
+                const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)got, 0), g1 = (uint32_t)__builtin_amdgcn_readlane((int)got, 1),
+                               g2 = (uint32_t)__builtin_amdgcn_readlane((int)got, 2);
+                const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)cnt, 0), k1 = (uint32_t)__builtin_amdgcn_readlane((int)cnt, 1),
+                               k2 = (uint32_t)__builtin_amdgcn_readlane((int)cnt, 2);
+                unsigned char *qbase = swap_mem + RT_SWAP_HDR_BYTES;
+                // 4. park the lanes of the other classes (every class in "new" mode)
+                if (cls < (uint32_t)RT_SWAP_CLASSES && allow_push && (mode_new || cls != cstar)) {
+                    const unsigned long long mc = cls == 0u ? m0 : (cls == 1u ? m1 : m2);
+                    const uint32_t g = cls == 0u ? g0 : (cls == 1u ? g1 : g2), c = cls == 0u ? k0 : (cls == 1u ? k1 : k2);
+                    const uint32_t idx = c + lane_rank(mc);
+                    if (g != 0u && idx < (uint32_t)RT_SWAP_CAP) {
+                        double *f64 = reinterpret_cast<double *>(qbase + cls * RT_SWAP_CLASS_BYTES) + idx;
+                        uint32_t *f32 = reinterpret_cast<uint32_t *>(qbase + cls * RT_SWAP_CLASS_BYTES + RT_SWAP_F64 * 8 * RT_SWAP_CAP) + idx;
+                        f64[0 * RT_SWAP_CAP] = ps.o.x;
+                        f64[1 * RT_SWAP_CAP] = ps.o.y;
+                        f64[2 * RT_SWAP_CAP] = ps.o.z;
+                        f64[3 * RT_SWAP_CAP] = ps.d.x;
+                        f64[4 * RT_SWAP_CAP] = ps.d.y;
+                        f64[5 * RT_SWAP_CAP] = ps.d.z;
+                        f64[6 * RT_SWAP_CAP] = ps.T.x;
+                        f64[7 * RT_SWAP_CAP] = ps.T.y;
+                        f64[8 * RT_SWAP_CAP] = ps.T.z;
+                        f64[9 * RT_SWAP_CAP] = __longlong_as_double((long long)ps.g.s0);
+                        f64[10 * RT_SWAP_CAP] = __longlong_as_double((long long)ps.g.s1);
+                        f64[11 * RT_SWAP_CAP] = tv.best_t;
+                        if (COUNT) f64[12 * RT_SWAP_CAP] = __longlong_as_double((long long)ps.g.draws);
+                        if (MEDIUM) f64[13 * RT_SWAP_CAP] = __longlong_as_double((long long)ps.g.base);
+                        f32[0 * RT_SWAP_CAP] = (uint32_t)ps.k;
+                        f32[1 * RT_SWAP_CAP] = tv.best_prim;
+                        f32[2 * RT_SWAP_CAP] = slot;
+                        if (GENERAL) f32[3 * RT_SWAP_CAP] = tv.best_sub;
+                        has_path = false;
+                        cls = kEmpty;
+                        if (COUNT) ++w_park;
+                    }
+                }
+                // 5. pull parked paths of the chosen class into the free lanes (newest first)
+                uint32_t pulled = 0u;
+                {
+                    const uint32_t gs = cstar == 0u ? g0 : (cstar == 1u ? g1 : g2), avail = cstar == 0u ? k0 : (cstar == 1u ? k1 : k2);
+                    if (!mode_new && gs != 0u && avail > 0u) {
+                        const unsigned long long mF = __ballot(cls == kEmpty);
+                        pulled = min((uint32_t)__popcll(mF), avail);
+                        const uint32_t r = lane_rank(mF);
+                        if (cls == kEmpty && r < pulled) {
+                            const uint32_t idx = avail - 1u - r;
+                            const double *f64 = reinterpret_cast<const double *>(qbase + cstar * RT_SWAP_CLASS_BYTES) + idx;
+                            const uint32_t *f32 =
+                                reinterpret_cast<const uint32_t *>(qbase + cstar * RT_SWAP_CLASS_BYTES + RT_SWAP_F64 * 8 * RT_SWAP_CAP) + idx;
+                            ps.o = rtl::mk(f64[0 * RT_SWAP_CAP], f64[1 * RT_SWAP_CAP], f64[2 * RT_SWAP_CAP]);
+                            ps.d = rtl::mk(f64[3 * RT_SWAP_CAP], f64[4 * RT_SWAP_CAP], f64[5 * RT_SWAP_CAP]);
+                            ps.T = rtl::mk(f64[6 * RT_SWAP_CAP], f64[7 * RT_SWAP_CAP], f64[8 * RT_SWAP_CAP]);
+                            ps.g.s0 = (uint64_t)__double_as_longlong(f64[9 * RT_SWAP_CAP]);
+                            ps.g.s1 = (uint64_t)__double_as_longlong(f64[10 * RT_SWAP_CAP]);
+                            tv.best_t = f64[11 * RT_SWAP_CAP];
+                            if (COUNT) ps.g.draws = (unsigned long long)__double_as_longlong(f64[12 * RT_SWAP_CAP]);
+                            if (MEDIUM) ps.g.base = (uint64_t)__double_as_longlong(f64[13 * RT_SWAP_CAP]);
+                            ps.k = (int32_t)f32[0 * RT_SWAP_CAP];
+                            tv.best_prim = f32[1 * RT_SWAP_CAP];
+                            slot = f32[2 * RT_SWAP_CAP];
+                            if (GENERAL) tv.best_sub = f32[3 * RT_SWAP_CAP];
+                            tv.cur = RT_CUR_DONE;
+                            tv.sp = 0;
+                            has_path = true;
+                            cls = cstar;
+                            if (COUNT) ++w_pull;
+                        }
+                    }
+                }
+                // 6. publish the new counts and release (the release orders this wave's queue traffic before it)
+                if (got != 0u) {
+                    uint32_t now = cnt;
+                    if (!mode_new && lane == cstar)
+                        now = cnt - pulled;
+                    else
+                        now = cnt + min(my_n, (uint32_t)RT_SWAP_CAP - cnt);
+                    __hip_atomic_store(&swap_hdr[lane], now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&swap_hdr[4u + lane], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                // 7. scatter what is in registers now: the chosen class, plus whatever could not be parked
+                if (COUNT && counting_lane) {
+                    if (mode_new) ++w_new; else ++w_class;
+                }
+                if (has_path && cls <= kInPlace) {
                     rtl::V3 rad;
-                    if (rtl::finish_segment<GENERAL, MEDIUM, TEXTURED>(L, &ps, tv, &rad)) {
+                    const bool fin = rtl::finish_segment<GENERAL, MEDIUM, TEXTURED>(L, &ps, tv, &rad, RT_BALL_ITERS, &pending);
+                    if (COUNT && !pending) {
+                        ++c_segs;
+                        ++w_scat;
+                        if (mode_new || cls != cstar) ++w_off;
+                    }
+                    if (fin) {
+                        double2 *o = reinterpret_cast<double2 *>(L.samples + (size_t)slot * 4);
+                        o[0] = make_double2(rad.x, rad.y);
+                        o[1] = make_double2(rad.z, 0.0);
+                        has_path = false;
+                        if (COUNT) {
+                            c_draws += ps.g.draws;
+                            ++c_samples;
+                        }
+                    }
+                }
+                part = cls != kNone;
+                need = part && !has_path;
+                do_refill = mode_new || __popcll(__ballot(need)) >= RT_SWAP_REFILL_MIN;
+            } else if (is_done) {
+                if (has_path) {
+                    rtl::V3 rad;
+                    const bool fin = rtl::finish_segment<GENERAL, MEDIUM, TEXTURED>(L, &ps, tv, &rad, RT_BALL_ITERS, &pending);
+                    if (COUNT && !pending) ++c_segs;
+                    if (fin) {
                         // one 32-byte aligned record per sample, two 16-byte stores: whole sectors,
                         // no read-modify-write of partially written lines at the memory side
                         double2 *o = reinterpret_cast<double2 *>(L.samples + (size_t)slot * 4);
@@ -166,7 +414,7 @@ __global__ __launch_bounds__(RT_BLOCK, (GENERAL ? RT_WAVES_PER_EU_GENERAL : RT_W
             t_fin += t1 - t0;
             // refill: lanes without a path take the next samples of the job queue.  Executed by the
             // whole wave (wave-uniform control flow) so the job state stays identical in every lane.
-            for (;;) {
+            while (do_refill) {
                 const unsigned long long m = __ballot(need);
                 if (m == 0ull) break;
                 if (job_left == 0u) {
@@ -211,11 +459,11 @@ __global__ __launch_bounds__(RT_BLOCK, (GENERAL ? RT_WAVES_PER_EU_GENERAL : RT_W
             }
             RT_STAMP(t0);
             t_ref += t0 - t1;
-            if (is_done) {
+            if (part && !pending) {
                 if (has_path)
                     rtl::begin_segment<GENERAL, MEDIUM, TEXTURED>(L, &ps, tv, st, &c_prims);
-                else
-                    tv.cur = RT_CUR_DEAD;
+                else // SWAP: an empty lane waits (DONE, no path) for a parked path or the next bulk refill
+                    tv.cur = (!SWAP || queue_empty) ? RT_CUR_DEAD : RT_CUR_DONE;
             }
             RT_STAMP(t1);
             t_beg += t1 - t0;
@@ -257,6 +505,15 @@ __global__ __launch_bounds__(RT_BLOCK, (GENERAL ? RT_WAVES_PER_EU_GENERAL : RT_W
         atomicAdd(&L.counters->nodes_visited, c_nodes);
         atomicAdd(&L.counters->prims_tested, c_prims);
         atomicAdd(&L.counters->rng_draws, c_draws);
+        if (SWAP) {
+            atomicAdd(&L.counters->swap_class_mode, w_class);
+            atomicAdd(&L.counters->swap_new_mode, w_new);
+            atomicAdd(&L.counters->swap_parked, w_park);
+            atomicAdd(&L.counters->swap_pulled, w_pull);
+            atomicAdd(&L.counters->swap_lock_busy, w_busy);
+            atomicAdd(&L.counters->swap_scattered, w_scat);
+            atomicAdd(&L.counters->swap_off_class, w_off);
+        }
         if (counting_lane) {
             atomicAdd(&L.counters->node_wave, c_nw);
             atomicAdd(&L.counters->node_lane, c_nl);
@@ -340,9 +597,9 @@ __global__ void probe_math_kernel(const double *a, const double *b, int n, doubl
 // ---- dispatch over the template instantiations ----
 typedef void (*KernelFn)(const RtLaunch);
 
-template <bool GENERAL, bool MEDIUM, bool TEXTURED>
+template <bool GENERAL, bool MEDIUM, bool TEXTURED, bool SWAP>
 KernelFn pick3(bool lens, bool count, bool ldsnodes) {
-#define RT_PICK(LN, C, LD) return render_kernel<GENERAL, MEDIUM, TEXTURED, LN, C, LD>
+#define RT_PICK(LN, C, LD) return render_kernel<GENERAL, MEDIUM, TEXTURED, LN, C, LD, SWAP>
     if (lens) {
         if (count) {
             if (ldsnodes) RT_PICK(true, true, true); else RT_PICK(true, true, false);
@@ -358,8 +615,11 @@ KernelFn pick3(bool lens, bool count, bool ldsnodes) {
     }
 #undef RT_PICK
 }
-KernelFn pick(unsigned features, bool lens, bool count, bool ldsnodes) {
-    return features == 0u ? pick3<false, false, false>(lens, count, ldsnodes) : pick3<true, true, true>(lens, count, ldsnodes);
+// lds_mode: bit 0 = node array copied to LDS, bit 1 = swap-at-shade queues
+KernelFn pick(unsigned features, bool lens, bool count, int lds_mode) {
+    const bool ldsnodes = (lds_mode & 1) != 0, swap = (lds_mode & 2) != 0;
+    if (features != 0u) return swap ? pick3<true, true, true, true>(lens, count, ldsnodes) : pick3<true, true, true, false>(lens, count, ldsnodes);
+    return swap ? pick3<false, false, false, true>(lens, count, ldsnodes) : pick3<false, false, false, false>(lens, count, ldsnodes);
 }
 
 } // namespace
@@ -368,7 +628,7 @@ KernelFn pick(unsigned features, bool lens, bool count, bool ldsnodes) {
 // `lds_bytes` of dynamic LDS (stack + optional node copy).
 extern "C" int rt_launch_render(const RtLaunch *L, unsigned features, int lens, int count, int ldsnodes, int blocks,
                                 unsigned lds_bytes, void *stream) {
-    KernelFn k = pick(features, lens != 0, count != 0, ldsnodes != 0);
+    KernelFn k = pick(features, lens != 0, count != 0, ldsnodes);
     if (lds_bytes > 48u * 1024u) { // dynamic LDS beyond the default limit must be requested explicitly
         hipError_t ea = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (ea != hipSuccess) return (int)ea;
@@ -379,11 +639,12 @@ extern "C" int rt_launch_render(const RtLaunch *L, unsigned features, int lens, 
 }
 
 extern "C" int rt_kernel_block_size(void) { return RT_BLOCK; }
+extern "C" unsigned rt_swap_lds_bytes(void) { return RT_SWAP_LDS_BYTES; }
 
 // occupancy-derived size of the persistent grid
 extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int ldsnodes, unsigned lds_bytes, int *blocks_per_cu,
                                     int *n_cu) {
-    KernelFn k = pick(features, lens != 0, count != 0, ldsnodes != 0);
+    KernelFn k = pick(features, lens != 0, count != 0, ldsnodes);
     int per_cu = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, RT_BLOCK, lds_bytes);
     if (e != hipSuccess) return (int)e;

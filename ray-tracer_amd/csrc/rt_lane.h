@@ -86,6 +86,28 @@ RT_HD double rng_range11(Rng &g) { // gen_range(-1.0, 1.0)
     ++g.draws;
     return rt_u64_to_range11(rt_xoroshiro_next(&g.s0, &g.s1));
 }
+// The same sampler with a bound on the iterations of THIS call: when the bound is hit the draws made so far stay
+// consumed and *ok is false; calling again simply continues the reference's loop (the rejected candidates are
+// never looked at again), so splitting the loop over several calls cannot change the accepted point or the stream.
+// A wave runs the loop until its slowest lane accepts (~5.5 iterations for 40 lanes, 1.9 on average per lane): the
+// kernel bounds it and lets the unlucky lanes finish in the next shade block.  max_iter <= 0: unbounded.
+RT_HD V3 random_in_unit_sphere_bounded(Rng &g, int max_iter, bool *ok) {
+    V3 p = mk(1.0, 1.0, 1.0);
+    int it = 0;
+    *ok = true;
+    while (dot(p, p) >= 1.0) {
+        if (max_iter > 0 && it == max_iter) {
+            *ok = false;
+            break;
+        }
+        ++it;
+        double a = rng_unit53(g);
+        double b = rng_unit53(g);
+        double c = rng_unit53(g);
+        p = mk(a * 2.0 - 1.0, b * 2.0 - 1.0, c * 2.0 - 1.0);
+    }
+    return p;
+}
 RT_HD V3 random_in_unit_sphere(Rng &g) { // src/util.rs:6-15
     V3 p = mk(1.0, 1.0, 1.0);
     while (dot(p, p) >= 1.0) {
@@ -511,7 +533,7 @@ RT_HD bool schlick_reflects(double c, double n1, double n2, double u) {
 // exactly those of its own material's scatter().
 template <bool TEXTURED>
 RT_HD bool shade(const RtLaunch &L, const RtMaterial &M, const Rec &rec, V3 d_in, Rng &g, V3 *o_out, V3 *d_out, V3 *att,
-                 V3 *emit) {
+                 V3 *emit, int ball_iters = 0, bool *pending = nullptr) {
     *emit = mk(0.0, 0.0, 0.0);
     V3 tex = ld3(M.rgb);
     if (TEXTURED && !M.solid) tex = texture_value(L, M.tex, rec.u, rec.v);
@@ -530,8 +552,14 @@ RT_HD bool shade(const RtLaunch &L, const RtMaterial &M, const Rec &rec, V3 d_in
     if (kind == RT_MAT_METAL || kind == RT_MAT_DIELECTRIC) uvn = normalized(d_in);
     // randomInUnitSphere() for the diffuse ones and fuzzy metal
     V3 ball = mk(0.0, 0.0, 0.0);
+    // (the sampler is the first consumer of the stream in these scatter()s, so a bounded call can be resumed)
+    bool ball_ok = true;
     if (kind == RT_MAT_LAMBERTIAN || kind == RT_MAT_ISOTROPIC || (kind == RT_MAT_METAL && M.param != 0.0))
-        ball = random_in_unit_sphere(g);
+        ball = random_in_unit_sphere_bounded(g, ball_iters, &ball_ok);
+    if (!ball_ok) {
+        *pending = true; // nothing but the stream has changed: shade this hit again later
+        return true;
+    }
 
     V3 v = ball; // Isotropic: randomInUnitSphere().normalized()
     bool norm = true;
@@ -633,8 +661,10 @@ RT_HD void leaf_step(const RtLaunch &L, PathState *ps, Trav &tv, Stack &st, unsi
 // render::color, src/render.rs:5-29, in its iterative form
 // L = sum_k (prod_{j<k} att_j) * e_k.  Returns true when the sample is finished, with its
 // radiance in *radiance.
+// ball_iters > 0 bounds the rejection sampler of this call; when the bound is hit *pending is set, nothing but the
+// stream has advanced and the same hit has to be finished again (the kernel does so in its next shade block).
 template <bool GENERAL, bool MEDIUM, bool TEXTURED>
-RT_HD bool finish_segment(const RtLaunch &L, PathState *ps, const Trav &tv, V3 *radiance) {
+RT_HD bool finish_segment(const RtLaunch &L, PathState *ps, const Trav &tv, V3 *radiance, int ball_iters = 0, bool *pending = nullptr) {
     constexpr bool UV = TEXTURED;
     *radiance = mk(0.0, 0.0, 0.0);
     if (tv.best_prim == 0xFFFFFFFFu) return true; // background is black (src/render.rs:21-28)
@@ -658,7 +688,12 @@ RT_HD bool finish_segment(const RtLaunch &L, PathState *ps, const Trav &tv, V3 *
     }
     V3 o2, d2, att, emit;
     const RtMaterial &M = L.materials[mat];
-    const bool cont = shade<TEXTURED>(L, M, rec, ps->d, ps->g, &o2, &d2, &att, &emit);
+    bool pend = false;
+    const bool cont = shade<TEXTURED>(L, M, rec, ps->d, ps->g, &o2, &d2, &att, &emit, ball_iters, &pend);
+    if (pend) {
+        *pending = true;
+        return false;
+    }
     if (M.kind == RT_MAT_DIFFUSE_LIGHT) *radiance = ps->T * emit;
     if (!cont) return true;
     ps->T = ps->T * att;

@@ -100,6 +100,8 @@ struct RtCounters {
     unsigned long long node_wave, node_lane, leaf_wave, leaf_lane, shade_wave, shade_lane;
     // s_memtime cycles spent inside each block, summed over waves (counting build only)
     unsigned long long node_cycles, leaf_cycles, shade_cycles, finish_cycles, refill_cycles, begin_cycles;
+    // swap-at-shade diagnostics (see include/rt_mi355x.h)
+    unsigned long long swap_class_mode, swap_new_mode, swap_parked, swap_pulled, swap_lock_busy, swap_scattered, swap_off_class;
 };
 
 // kernel arguments (passed by value)

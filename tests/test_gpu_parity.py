@@ -410,3 +410,23 @@ def test_specular_furnace_matches_oracle(rt, scenes, oracle, gpu_device, mat):
     want = 1.0 if mat == "dielectric" else 0.8
     assert np.all(np.abs(img[4, 4] - want) <= 1e-12), img[4, 4]
     assert np.array_equal(img[0, 0], [1.0, 1.0, 1.0])
+
+
+@pytest.mark.parametrize("scene", ["book_one", "cornell", "cover"])
+def test_swap_at_shade_never_changes_a_result(rt, scenes, gpu_device, monkeypatch, scene):
+    """The kernels with the swap-at-shade queues (default) and the ones without (RT_SWAP=0) move paths between
+    lanes and waves differently; every sample still consumes its own stream, so the images are identical bits,
+    and so are the algorithmic counters (segments, node steps, primitive tests, draws)."""
+    W, H, spp = 96, 64, 12
+    desc = {"book_one": lambda: scenes.book_one(1, W / H), "cornell": lambda: scenes.cornell(W / H),
+            "cover": lambda: scenes.cover(1, W / H)}[scene]()
+    sc, cam = scenes.build_product(desc, device=gpu_device)
+    monkeypatch.setenv("RT_SWAP", "0")
+    plain, c0 = sc.render(cam, W, H, spp, 50, seed=5, counters=True)
+    monkeypatch.setenv("RT_SWAP", "1")
+    swapped, c1 = sc.render(cam, W, H, spp, 50, seed=5, counters=True)
+    assert np.array_equal(plain, swapped)
+    for k in ("samples", "segments", "nodes_visited", "prims_tested", "rng_draws"):
+        assert c0[k] == c1[k], k
+    assert c0["swap_scattered"] == 0 and c1["swap_scattered"] > 0
+    assert c1["swap_parked"] == c1["swap_pulled"]  # nothing is left behind in a queue
