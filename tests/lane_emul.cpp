@@ -121,3 +121,30 @@ extern "C" int lane_emul_render(rt_scene *s, const rt_camera *cam, int W, int H,
     if (stack_high) *stack_high = hw;
     return 0;
 }
+
+// The resumable, bounded form of the unit-ball sampler (rtl::random_in_unit_sphere_bounded, used by kernels built
+// with RT_BALL_ITERS > 0) against the plain loop: same accepted point, same generator state, same number of draws,
+// however the iterations are split over calls.  Returns the number of bounded calls it took.
+extern "C" int lane_emul_ball_check(uint64_t seed, uint64_t stream, int max_iter, double ref_point[3], double bounded_point[3],
+                                    uint64_t ref_state[3], uint64_t bounded_state[3]) {
+    rtl::Rng a, b;
+    a.base = b.base = rt_mix64(seed) + (stream << RT_RNG_STREAM_SHIFT) * RT_RNG_GAMMA;
+    rt_rng_seed_state(a.base, &a.s0, &a.s1);
+    rt_rng_seed_state(b.base, &b.s0, &b.s1);
+    a.draws = b.draws = 0;
+    const rtl::V3 p = rtl::random_in_unit_sphere(a);
+    rtl::V3 q;
+    int calls = 0;
+    for (;;) {
+        bool ok = false;
+        q = rtl::random_in_unit_sphere_bounded(b, max_iter, &ok);
+        ++calls;
+        if (ok) break;
+        if (calls > 1000) return -1;
+    }
+    ref_point[0] = p.x, ref_point[1] = p.y, ref_point[2] = p.z;
+    bounded_point[0] = q.x, bounded_point[1] = q.y, bounded_point[2] = q.z;
+    ref_state[0] = a.s0, ref_state[1] = a.s1, ref_state[2] = a.draws;
+    bounded_state[0] = b.s0, bounded_state[1] = b.s1, bounded_state[2] = b.draws;
+    return calls;
+}

@@ -28,3 +28,15 @@ def render(scene, cam, W, H, spp, max_depth, seed=1, region=None, sample_pixel=N
     names = ("samples", "segments", "nodes_visited", "prims_tested", "rng_draws")
     res = (out, dict(zip(names, [int(c) for c in cnt])), hw.value)
     return res + (samples,) if sample_pixel else res
+
+
+_LIB.lane_emul_ball_check.restype = C.c_int
+_LIB.lane_emul_ball_check.argtypes = [C.c_uint64, C.c_uint64, C.c_int, _DP, _DP, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+
+
+def ball_check(seed, stream, max_iter):
+    """-> (calls, reference point, bounded point, reference (s0, s1, draws), bounded (s0, s1, draws))."""
+    p, q = np.zeros(3), np.zeros(3)
+    a, b = (C.c_uint64 * 3)(), (C.c_uint64 * 3)()
+    calls = _LIB.lane_emul_ball_check(seed, stream, max_iter, p.ctypes.data_as(_DP), q.ctypes.data_as(_DP), a, b)
+    return calls, p, q, tuple(int(v) for v in a), tuple(int(v) for v in b)

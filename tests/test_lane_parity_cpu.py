@@ -94,3 +94,18 @@ def test_max_depth_zero_is_black(scenes, lane_emul):
     sc, cam = scenes.build_product(scenes.book_one(1, 1.5), device=-1)
     img, *_ = lane_emul.render(sc, cam, 16, 8, 2, 0)
     assert np.array_equal(img, np.zeros((8, 16, 3)))
+
+
+def test_bounded_ball_sampler_is_the_same_loop(lane_emul):
+    """random_in_unit_sphere_bounded split over several calls (1, 2 or 3 iterations each) accepts the same point
+    and leaves the same stream as the reference's single loop (src/util.rs:6-15); some streams need several calls."""
+    most = 0
+    for stream in range(400):
+        for k in (1, 2, 3):
+            calls, p, q, a, b = lane_emul.ball_check(7, stream, k)
+            assert calls >= 1 and np.array_equal(p, q) and a == b, (stream, k)
+            assert a[2] % 3 == 0 and (a[2] // 3 + k - 1) // k == calls  # draws = 3 per iteration; calls = ceil(iter / k)
+            most = max(most, calls)
+    assert most >= 4
+    calls, p, q, a, b = lane_emul.ball_check(7, 5, 0)  # 0 = unbounded
+    assert calls == 1 and np.array_equal(p, q) and a == b
