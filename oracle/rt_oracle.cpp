@@ -8,7 +8,9 @@
 // "reference" form it is also the CPU baseline that bench.py times.
 //
 // Parity unpinned against the Rust binary (cannot be built here; no golden
-// vectors upstream); pinned by hand-derived KATs in tests/test_oracle_kat.py.
+// vectors upstream); pinned by hand-derived KATs in tests/test_oracle_kat.py and,
+// statistically, by the reference's one published render (cover.png): region
+// means of the 8-bit picture at 800x800x1000, tests/test_cover_png.py.
 
 #include "rt_oracle.h"
 

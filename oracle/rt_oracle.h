@@ -18,7 +18,10 @@
  * known-answer tests taken straight from the cited formulas
  * (tests/test_oracle_kat.py); against the real Rust
  * binary parity is statistical only ("parity unpinned" in the sense of the
- * task statement -- see DESIGN.md).
+ * task statement -- see DESIGN.md): the one output the reference ships, its
+ * README figure cover.png (examples/main.rs, 800x800, 1000 spp, unseeded), is
+ * matched in region means of the 8-bit picture (tests/test_cover_png.py,
+ * fixture tests/golden/cover_png_regions.json).
  */
 #ifndef RT_ORACLE_H
 #define RT_ORACLE_H

@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Region statistics of the reference's published render -> tests/golden/cover_png_regions.json.
+
+/root/reference/cover.png (800x800) is the only output of the reference that ships with it: one run of
+examples/main.rs at 1000 spp.  The run is unseeded, so it is no pixel golden, but most of the scene is fixed
+(camera, light, the four big spheres, the medium inside the blue one); only the floor heights, the cloud of small
+spheres and the earth texture file vary.  This script reads the PNG (zlib only; no image library in the image)
+and stores mean / std of the 8-bit channels over hand-picked regions, in PNG coordinates (x right, y down).
+Run it in the build container (it needs /root/reference); the tests only read the JSON.
+"""
+import json
+import struct
+import zlib
+from pathlib import Path
+
+import numpy as np
+
+SRC = Path("/root/reference/cover.png")
+DST = Path(__file__).resolve().parent / "cover_png_regions.json"
+
+# name: (x0, y0, x1, y1), what it shows, how far a correct render may be off (8-bit levels, per channel mean)
+REGIONS = {
+    "light": ((220, 30, 400, 90), "the 7,7,7 rectangle light seen directly: saturates", 0.0),
+    "background_mid": ((250, 150, 400, 350), "nothing behind it: exactly black (no fog in this render)", 0.0),
+    "background_right": ((650, 100, 790, 250), "nothing behind it: exactly black", 0.0),
+    "orange_core": ((117, 198, 177, 258), "lambertian (0.7,0.3,0.1) sphere lit by floor bounce", 1.5),
+    "orange_small": ((132, 213, 162, 243), "30x30 centre of the same sphere (CPU-sized)", 2.0),
+    "metal_core": ((650, 540, 710, 600), "metal (0.8,0.8,0.9) fuzz 1 sphere", 3.0),
+    "blue_core": ((165, 540, 265, 640), "dielectric shell + isotropic (0.2,0.4,0.9) medium, density 0.03", 5.0),
+    "blue_small": ((205, 580, 225, 600), "20x20 centre of the same sphere (CPU-sized)", 6.0),
+    "cluster": ((440, 260, 600, 400), "1000 white r=10 spheres at random places in a fixed box", 8.0),
+    "floor_bottom": ((0, 700, 800, 800), "boxes of random height (1..101)", 14.0),
+    "whole": ((0, 0, 800, 800), "everything, incl. the earth texture this repo replaces by a synthetic one", 6.0),
+}
+
+
+def read_png_rgb(path):
+    b = path.read_bytes()
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, hdr = 8, b"", None
+    while pos < len(b):
+        n, typ = struct.unpack(">I4s", b[pos:pos + 8])
+        data = b[pos + 8:pos + 8 + n]
+        pos += 12 + n
+        if typ == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", data)
+        elif typ == b"IDAT":
+            idat += data
+        elif typ == b"IEND":
+            break
+    w, h, depth, ctype, _, _, interlace = hdr
+    assert depth == 8 and interlace == 0 and ctype in (2, 6)
+    bpp = 4 if ctype == 6 else 3
+    raw, stride = zlib.decompress(idat), w * bpp
+    out = np.zeros((h, stride), dtype=np.uint8)
+    prev = np.zeros(stride, dtype=np.int32)
+    p = 0
+    for y in range(h):
+        f = raw[p]
+        line = np.frombuffer(raw[p + 1:p + 1 + stride], dtype=np.uint8).astype(np.int32)
+        p += 1 + stride
+        if f == 0:
+            cur = line
+        elif f == 2:
+            cur = (line + prev) & 255
+        else:
+            cur = np.zeros(stride, dtype=np.int32)
+            for i in range(stride):
+                a = cur[i - bpp] if i >= bpp else 0
+                up = prev[i]
+                c = prev[i - bpp] if i >= bpp else 0
+                if f == 1:
+                    pred = a
+                elif f == 3:
+                    pred = (a + up) >> 1
+                else:
+                    pa, pb, pc = abs(up - c), abs(a - c), abs(a + up - 2 * c)
+                    pred = a if (pa <= pb and pa <= pc) else (up if pb <= pc else c)
+                cur[i] = (line[i] + pred) & 255
+        out[y] = cur
+        prev = cur
+    return out.reshape(h, w, bpp)[:, :, :3]
+
+
+def main():
+    im = read_png_rgb(SRC)
+    assert im.shape == (800, 800, 3)
+    res = {"source": "cover.png of aiifabbf/ray-tracer (README figure; examples/main.rs, 800x800, 1000 spp, unseeded)",
+           "conversion": "min(sqrt(c) * 255, 255) as u8 (examples/main.rs:113-121); rows top-down",
+           "coordinates": "x right, y down (PNG)", "regions": {}}
+    for name, ((x0, y0, x1, y1), what, tol) in REGIONS.items():
+        r = im[y0:y1, x0:x1].reshape(-1, 3).astype(np.float64)
+        res["regions"][name] = {"box": [x0, y0, x1, y1], "what": what, "tolerance_levels": tol,
+                                "mean": [round(v, 4) for v in r.mean(0)], "std": [round(v, 4) for v in r.std(0)],
+                                "min": [int(v) for v in r.min(0)], "max": [int(v) for v in r.max(0)]}
+    DST.write_text(json.dumps(res, indent=1) + "\n")
+    print("wrote", DST)
+
+
+if __name__ == "__main__":
+    main()
