@@ -24,7 +24,8 @@ extern "C" int rt_launch_render(const RtLaunch *L, unsigned features, int lens, 
                                 unsigned lds_bytes, void *stream);
 extern "C" int rt_launch_reduce(const double *samples, double *tiles, int n_owned_tiles, int s_count, int first_pass, int last_pass,
                                 int spp, int width, int height, int shard_index, int shard_count, void *stream);
-extern "C" int rt_kernel_block_size(void);
+extern "C" int rt_kernel_block_size(unsigned features);
+extern "C" int rt_kernel_waves_per_simd(unsigned features);
 extern "C" unsigned rt_swap_lds_bytes(void);
 extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int ldsnodes, unsigned lds_bytes, int *blocks_per_cu,
                                     int *n_cu);
@@ -337,7 +338,7 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     fill_launch(s, cam, p, n_owned, &L);
     // dynamic LDS: the traversal stack, plus a copy of the node array when three workgroups
     // of it still fit the CU's 160 KiB (book-one: 31 KB of nodes + 12 KB of stack)
-    const unsigned block = (unsigned)rt_kernel_block_size();
+    const unsigned block = (unsigned)rt_kernel_block_size(feat);
     const unsigned stack_bytes = (unsigned)L.stack_entries * block * 4u;
     const unsigned node_bytes = (unsigned)(s->flat.nodes.size() * sizeof(RtNode));
     const char *no_lds = std::getenv("RT_NO_LDS_NODES");
@@ -345,8 +346,9 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     const char *swap_env = std::getenv("RT_SWAP");
     const int swap = !(swap_env && *swap_env == '0');
     const unsigned swap_bytes = swap ? rt_swap_lds_bytes() : 0u;
-    // keep 16 waves per CU resident: (1024 / block) workgroups, each with its own node copy
-    const int ldsnodes = node_bytes > 0 && (1024u / block) * (stack_bytes + node_bytes + swap_bytes) <= 160u * 1024u &&
+    // keep the kernel family's full occupancy resident: that many workgroups per CU, each with its own node copy
+    const unsigned groups_per_cu = std::max(1u, (unsigned)rt_kernel_waves_per_simd(feat) * 256u / block);
+    const int ldsnodes = node_bytes > 0 && groups_per_cu * (stack_bytes + node_bytes + swap_bytes) <= 160u * 1024u &&
                          !(no_lds && *no_lds == '1');
     const unsigned lds_bytes = stack_bytes + (ldsnodes ? node_bytes : 0u) + swap_bytes;
     const int lds_mode = (ldsnodes ? 1 : 0) | (swap ? 2 : 0);

@@ -37,6 +37,15 @@
 #ifndef RT_BLOCK
 #define RT_BLOCK 512 /* threads per workgroup: 8 waves share one LDS copy of the node array */
 #endif
+#ifndef RT_BLOCK_GENERAL
+#define RT_BLOCK_GENERAL 512 /* general kernel with media / textures: 245 VGPRs, 2 waves per SIMD = one workgroup per CU */
+#endif
+// the general kernel without medium / texture code (Cornell box) needs 157 VGPRs = 3 waves per SIMD: three workgroups
+// of 4 waves (one per SIMD) per CU.  6-wave groups (384 threads) do NOT work: the second group no longer fits the
+// SIMDs the first one loaded unevenly (1028 vs 1701 Msamples/s on the Cornell box)
+#ifndef RT_BLOCK_LEAN
+#define RT_BLOCK_LEAN 256
+#endif
 
 // vote thresholds (lanes).  A block runs when at least this many lanes wait for
 // it, or when no cheaper block has work.
@@ -61,6 +70,9 @@
 #endif
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 4 /* spheres-only kernel: 105 VGPRs fit 4 waves per SIMD */
+#endif
+#ifndef RT_WAVES_PER_EU_LEAN
+#define RT_WAVES_PER_EU_LEAN 3 /* general prims without media / textures: 157 VGPRs */
 #endif
 #ifndef RT_WAVES_PER_EU_GENERAL
 #define RT_WAVES_PER_EU_GENERAL 2 /* general kernel (matrices, cubes, media, textures) needs the registers */
@@ -101,17 +113,25 @@
 
 namespace {
 
+template <int BLOCK>
 struct LdsStack {
     uint32_t *base; // &stack[threadIdx.x]
     __device__ __forceinline__ void push(int32_t &sp, uint32_t v) {
-        base[sp * RT_BLOCK] = v;
+        base[sp * BLOCK] = v;
         ++sp;
     }
     __device__ __forceinline__ uint32_t pop(int32_t &sp) {
         --sp;
-        return base[sp * RT_BLOCK];
+        return base[sp * BLOCK];
     }
 };
+// workgroup size and waves per SIMD of each kernel family
+__host__ __device__ constexpr int block_of(bool general, bool medium) {
+    return general ? (medium ? RT_BLOCK_GENERAL : RT_BLOCK_LEAN) : RT_BLOCK;
+}
+__host__ __device__ constexpr int waves_of(bool general, bool medium) {
+    return general ? (medium ? RT_WAVES_PER_EU_GENERAL : RT_WAVES_PER_EU_LEAN) : RT_WAVES_PER_EU;
+}
 
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) { // set bits below this lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -124,22 +144,23 @@ __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__bui
 extern __shared__ __attribute__((aligned(16))) unsigned char rt_lds[];
 
 template <bool GENERAL, bool MEDIUM, bool TEXTURED, bool LENS, bool COUNT, bool LDSNODES, bool SWAP>
-__global__ __launch_bounds__(RT_BLOCK, (GENERAL ? RT_WAVES_PER_EU_GENERAL : RT_WAVES_PER_EU)) void render_kernel(const RtLaunch L) {
+__global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM)) void render_kernel(const RtLaunch L) {
+    constexpr int kBlock = block_of(GENERAL, MEDIUM);
     uint32_t *stack_mem = reinterpret_cast<uint32_t *>(rt_lds);
-    LdsStack st;
+    LdsStack<kBlock> st;
     st.base = stack_mem + threadIdx.x;
     const RtNode *nodes = L.nodes;
     const unsigned node_lds_bytes = LDSNODES ? (unsigned)L.n_nodes * (unsigned)sizeof(RtNode) : 0u;
     // swap queues: header {count[3], pad, lock[3], pad}, then per class RT_SWAP_F64 arrays of CAP doubles and
     // RT_SWAP_F32 arrays of CAP words (field-major: consecutive entries are consecutive addresses)
-    unsigned char *swap_mem = rt_lds + (size_t)L.stack_entries * RT_BLOCK * sizeof(uint32_t) + node_lds_bytes;
+    unsigned char *swap_mem = rt_lds + (size_t)L.stack_entries * kBlock * sizeof(uint32_t) + node_lds_bytes;
     uint32_t *swap_hdr = reinterpret_cast<uint32_t *>(swap_mem);
     if (SWAP && threadIdx.x < RT_SWAP_HDR_BYTES / 4u) swap_hdr[threadIdx.x] = 0u;
     if (LDSNODES) {
-        uint4 *dst = reinterpret_cast<uint4 *>(rt_lds + (size_t)L.stack_entries * RT_BLOCK * sizeof(uint32_t));
+        uint4 *dst = reinterpret_cast<uint4 *>(rt_lds + (size_t)L.stack_entries * kBlock * sizeof(uint32_t));
         const uint4 *src = reinterpret_cast<const uint4 *>(L.nodes);
         const int n16 = L.n_nodes * (int)(sizeof(RtNode) / 16);
-        for (int i = (int)threadIdx.x; i < n16; i += RT_BLOCK) dst[i] = src[i];
+        for (int i = (int)threadIdx.x; i < n16; i += kBlock) dst[i] = src[i];
         nodes = reinterpret_cast<const RtNode *>(dst);
     }
     if (LDSNODES || SWAP) __syncthreads();
@@ -618,11 +639,15 @@ KernelFn pick3(bool lens, bool count, bool ldsnodes) {
 // lds_mode: bit 0 = node array copied to LDS, bit 1 = swap-at-shade queues
 KernelFn pick(unsigned features, bool lens, bool count, int lds_mode) {
     const bool ldsnodes = (lds_mode & 1) != 0, swap = (lds_mode & 2) != 0;
+    // general prims only (matrices, rectangles, cubes: the Cornell box): no medium / texture code in the kernel
+    if (features == 1u) return swap ? pick3<true, false, false, true>(lens, count, ldsnodes) : pick3<true, false, false, false>(lens, count, ldsnodes);
     if (features != 0u) return swap ? pick3<true, true, true, true>(lens, count, ldsnodes) : pick3<true, true, true, false>(lens, count, ldsnodes);
     return swap ? pick3<false, false, false, true>(lens, count, ldsnodes) : pick3<false, false, false, false>(lens, count, ldsnodes);
 }
 
 } // namespace
+
+extern "C" int rt_kernel_block_size(unsigned features);
 
 // feature bits: 1 = general prims, 2 = media, 4 = textured.  `blocks` persistent workgroups,
 // `lds_bytes` of dynamic LDS (stack + optional node copy).
@@ -633,12 +658,17 @@ extern "C" int rt_launch_render(const RtLaunch *L, unsigned features, int lens, 
         hipError_t ea = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (ea != hipSuccess) return (int)ea;
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(RT_BLOCK), lds_bytes, (hipStream_t)stream, *L);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3((unsigned)rt_kernel_block_size(features)), lds_bytes, (hipStream_t)stream, *L);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
 
-extern "C" int rt_kernel_block_size(void) { return RT_BLOCK; }
+// threads per workgroup of the kernel family that serves these feature bits (see pick())
+extern "C" int rt_kernel_block_size(unsigned features) { return features == 0u ? RT_BLOCK : (features == 1u ? RT_BLOCK_LEAN : RT_BLOCK_GENERAL); }
+// waves per SIMD that family is compiled for: (that x 4 SIMDs x 64) / block size workgroups share a CU's LDS
+extern "C" int rt_kernel_waves_per_simd(unsigned features) {
+    return features == 0u ? RT_WAVES_PER_EU : (features == 1u ? RT_WAVES_PER_EU_LEAN : RT_WAVES_PER_EU_GENERAL);
+}
 extern "C" unsigned rt_swap_lds_bytes(void) { return RT_SWAP_LDS_BYTES; }
 
 // occupancy-derived size of the persistent grid
@@ -646,7 +676,7 @@ extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int 
                                     int *n_cu) {
     KernelFn k = pick(features, lens != 0, count != 0, ldsnodes);
     int per_cu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, RT_BLOCK, lds_bytes);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k, rt_kernel_block_size(features), lds_bytes);
     if (e != hipSuccess) return (int)e;
     int dev = 0;
     hipDeviceProp_t prop;
