@@ -430,3 +430,35 @@ def test_swap_at_shade_never_changes_a_result(rt, scenes, gpu_device, monkeypatc
         assert c0[k] == c1[k], k
     assert c0["swap_scattered"] == 0 and c1["swap_scattered"] > 0
     assert c1["swap_parked"] == c1["swap_pulled"]  # nothing is left behind in a queue
+
+
+def test_lean_general_kernel_on_a_large_scene(rt, scenes, oracle, gpu_device):
+    """Hundreds of rotated cubes and rectangles, lambertian / metal / glass, no medium and no texture: the general
+    kernel family without that code (256-thread groups, 3 waves per SIMD) with a real tree in LDS."""
+    rng = np.random.default_rng(21)
+    d = scenes.SceneDesc()
+    mats = [d.lambertian_rgb(rng.uniform(0.2, 0.9, 3)) for _ in range(4)] + [d.mat("metal", d.tex_solid((0.8, 0.8, 0.7)), 0.2),
+                                                                              d.mat("dielectric", 1.5)]
+    axes = ((1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0))
+    for i in range(18):
+        for j in range(18):
+            M = scenes.mat4_multiplied(scenes.mat4_translation((i * 1.5 - 13.0 + rng.uniform(0, 0.4), rng.uniform(0.0, 0.6), j * 1.5 - 13.0)),
+                                       scenes.mat4_rotation(rng.uniform(0, 3.0), axes[int(rng.integers(3))]))
+            if (i + j) % 5 == 0:
+                g = d.geom("rectangle", rng.uniform(0.5, 1.2), rng.uniform(0.5, 1.2))
+            elif (i + j) % 5 == 1:
+                g = d.geom("sphere", rng.uniform(0.3, 0.6))
+            else:
+                g = d.geom("cube", rng.uniform(0.4, 1.0), rng.uniform(0.4, 1.0), rng.uniform(0.4, 1.0))
+            d.sprite(g, mats[int(rng.integers(len(mats)))], M)
+    d.sprite(d.geom("rectangle", 60.0, 60.0), d.lambertian_rgb((0.5, 0.5, 0.5)),
+             scenes.mat4_multiplied(scenes.mat4_translation((0.0, -0.6, 0.0)), scenes.mat4_rotation(scenes.radians(90.0), axes[0])))
+    d.sprite(d.geom("sphere", 400.0), d.mat("diffuse_light", d.tex_solid((0.7, 0.8, 1.0))), None)
+    d.camera = ((22.0, 9.0, 12.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 0.6, 1.5, 25.0, 0.03)
+    sc, cam = scenes.build_product(d, device=gpu_device)
+    info = sc.info()
+    assert info["feature_mask"] & rt.RT_FEAT_GENERAL and not info["feature_mask"] & (rt.RT_FEAT_MEDIUM | rt.RT_FEAT_TEXTURED)
+    assert info["n_nodes"] > 300
+    img = sc.render(cam, 96, 64, 6, 50, seed=9)
+    ref = oracle.build_oracle(d).render(96, 64, 6, 50, seed=9, iterative=True, nthreads=8)
+    _close(img, ref, max_bad=2)
