@@ -185,10 +185,12 @@ def main():
         achieved = bytes_per_sample * launch_samples / (kernel_avg_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes of this same command,
         # tools/profile.sh; corrected as MI355X_MICROARCH.md prescribes); only valid for the profiled workload
-        traffic = None
+        traffic, valu = None, None
         tf = ROOT / "profiles" / "pmc_traffic.json"
         if tf.exists() and (a.scene, W, H, spp, depth, world) == ("book_one", 1200, 800, 500, 100, 1):
-            traffic = json.load(open(tf))["hbm_bytes_per_launch"]
+            pmc = json.load(open(tf))
+            traffic = pmc["hbm_bytes_per_launch"]
+            valu = pmc.get("valu")  # what actually bounds the kernel (same profile): VALU issue
         res = {
             "metric": "Msamples/sec (pixels x spp), book-one 1200x800x500spp" if a.scene == "book_one" else f"Msamples/sec (pixels x spp), {a.scene}",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -199,7 +201,7 @@ def main():
                        "scene_seed": a.scene_seed, "render_seed": a.seed, "n_spheres": info["n_prims"],
                        "bvh_nodes": info["n_nodes"], "sharding": f"8x8 tiles, tile_id % {world}, one RCCL gather"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu_pmc": valu,
                          "note": "algorithmic bytes are served from LDS/L1/L2 (scene < 100 KB): the kernel is VALU-issue bound, see DESIGN.md",
                          "kernel": "render_kernel", "kernel_ms": kernel_avg_ms, "algorithmic_bytes_per_sample": bytes_per_sample,
                          "segments_per_sample": cnt["segments"] / ns, "nodes_per_sample": cnt["nodes_visited"] / ns,
