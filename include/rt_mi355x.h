@@ -188,6 +188,11 @@ int rt_last_kernel_ms(rt_scene *, float *ms);
  *      gamma 2, clamp high, truncate, NaN / negative -> 255 (Q13); rows top-down ---- */
 void rt_tonemap_rgb8(const double *rgb, size_t n_pixels, uint8_t *out_rgb8);
 int rt_write_ppm_p3(const char *path, const double *rgb, int width, int height);
+/* the PNG path of examples/main.rs:105-135: RGBA8, alpha 255, put_pixel(x, height - 1 - y), channel =
+ * (c.sqrt() * 255.0).min(255.0) as u8 (NaN -> 255 through f64::min, the cast saturates); non-interlaced,
+ * uncompressed (stored deflate blocks) -- any PNG reader decodes the same pixels the `image` crate would write */
+void rt_tonemap_png8(const double *rgb, size_t n_pixels, uint8_t *out_rgb8);
+int rt_write_png_rgba8(const char *path, const double *rgb, int width, int height);
 
 /* ---- inspection of the committed flat scene (tests, algorithmic-byte accounting) ---- */
 typedef struct rt_scene_info {

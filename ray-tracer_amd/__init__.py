@@ -107,6 +107,8 @@ ABI = {
     "rt_last_kernel_ms": (C.c_int, [_VP, C.POINTER(C.c_float)]),
     "rt_tonemap_rgb8": (None, [_DP, C.c_size_t, C.POINTER(C.c_uint8)]),
     "rt_write_ppm_p3": (C.c_int, [C.c_char_p, _DP, C.c_int, C.c_int]),
+    "rt_write_png_rgba8": (C.c_int, [C.c_char_p, _DP, C.c_int, C.c_int]),
+    "rt_tonemap_png8": (None, [_DP, C.c_size_t, C.POINTER(C.c_uint8)]),
     "rt_scene_get_info": (C.c_int, [_VP, C.POINTER(rt_scene_info)]),
     "rt_scene_copy_nodes": (C.c_int, [_VP, _DP, C.c_int]),
     "rt_scene_prim_bounds": (C.c_int, [_VP, C.c_int, _DP]),
@@ -332,6 +334,20 @@ def write_ppm_p3(path, img: np.ndarray):
     a = np.ascontiguousarray(img, dtype=np.float64)
     h, w, _ = a.shape
     _check(lib().rt_write_ppm_p3(os.fsencode(str(path)), _dp(a), w, h))
+
+
+def write_png_rgba8(path, img: np.ndarray):
+    """examples/main.rs:105-135: RGBA8 PNG, rows top-down, channel = min(sqrt(c) * 255, 255) as u8"""
+    a = np.ascontiguousarray(img, dtype=np.float64)
+    h, w, _ = a.shape
+    _check(lib().rt_write_png_rgba8(os.fsencode(str(path)), _dp(a), w, h))
+
+
+def tonemap_png8(img: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(img, dtype=np.float64)
+    out = np.zeros(a.shape, dtype=np.uint8)
+    lib().rt_tonemap_png8(_dp(a), a.size // 3, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
 
 
 def device_count() -> int:

@@ -591,6 +591,30 @@ int rt_write_ppm_p3(const char *path, const double *rgb, int width, int height) 
     return RT_OK;
 }
 
+void rt_tonemap_png8(const double *rgb, size_t n_pixels, uint8_t *out) {
+    for (size_t i = 0; i < n_pixels * 3; ++i) out[i] = rt::png_channel(rgb[i]);
+}
+
+int rt_write_png_rgba8(const char *path, const double *rgb, int width, int height) { // examples/main.rs:105-135
+    if (!path || !rgb || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "bad argument");
+    std::vector<uint8_t> rgba((size_t)width * (size_t)height * 4);
+    for (int y = 0; y < height; ++y) // put_pixel(x, height - 1 - y, ..): rows top-down while y is up
+        for (int x = 0; x < width; ++x) {
+            const double *px = rgb + ((size_t)y * (size_t)width + (size_t)x) * 3;
+            uint8_t *o = rgba.data() + ((size_t)(height - 1 - y) * (size_t)width + (size_t)x) * 4;
+            o[0] = rt::png_channel(px[0]);
+            o[1] = rt::png_channel(px[1]);
+            o[2] = rt::png_channel(px[2]);
+            o[3] = 255;
+        }
+    const std::vector<uint8_t> png = rt::encode_png_rgba8(rgba.data(), width, height);
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return fail(RT_ERR_INVALID, std::string("cannot open ") + path);
+    const bool ok = std::fwrite(png.data(), 1, png.size(), f) == png.size();
+    std::fclose(f);
+    return ok ? RT_OK : fail(RT_ERR_INVALID, std::string("short write to ") + path);
+}
+
 int rt_scene_get_info(const rt_scene *s, rt_scene_info *out) {
     if (!s || !out) return fail(RT_ERR_INVALID, "null argument");
     if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");

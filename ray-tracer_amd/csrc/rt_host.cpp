@@ -149,6 +149,90 @@ void camera_perspective(RtCameraD *out, const double eye[3], const double center
     out->lens_radius = lens;
 }
 
+uint8_t png_channel(double c) { // examples/main.rs:116-118
+    // f64::min returns the non-NaN operand, so sqrt(negative) = NaN becomes 255.0 before the cast
+    const double r = std::sqrt(c) * 255.0;
+    const double v = std::isnan(r) ? 255.0 : (r < 255.0 ? r : 255.0);
+    return v <= 0.0 ? (uint8_t)0 : (uint8_t)v; // `as u8`: truncation toward zero, saturating
+}
+
+namespace {
+uint32_t crc32_of(const uint8_t *p, size_t n, uint32_t crc) {
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        ready = true;
+    }
+    crc = ~crc;
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+    return ~crc;
+}
+void put_be32(std::vector<uint8_t> &v, uint32_t x) {
+    v.push_back((uint8_t)(x >> 24));
+    v.push_back((uint8_t)(x >> 16));
+    v.push_back((uint8_t)(x >> 8));
+    v.push_back((uint8_t)x);
+}
+void put_chunk(std::vector<uint8_t> &png, const char type[4], const std::vector<uint8_t> &data) {
+    put_be32(png, (uint32_t)data.size());
+    const size_t at = png.size();
+    png.insert(png.end(), type, type + 4);
+    png.insert(png.end(), data.begin(), data.end());
+    put_be32(png, crc32_of(png.data() + at, png.size() - at, 0u));
+}
+} // namespace
+
+std::vector<uint8_t> encode_png_rgba8(const uint8_t *rgba, int width, int height) {
+    // scanlines: filter byte 0 + width * 4 bytes
+    const size_t stride = (size_t)width * 4;
+    std::vector<uint8_t> raw;
+    raw.reserve((stride + 1) * (size_t)height);
+    for (int y = 0; y < height; ++y) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgba + (size_t)y * stride, rgba + (size_t)(y + 1) * stride);
+    }
+    // zlib stream of stored (uncompressed) deflate blocks
+    std::vector<uint8_t> z;
+    z.push_back(0x78);
+    z.push_back(0x01);
+    size_t pos = 0;
+    do {
+        const size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n == raw.size() ? 1 : 0);
+        z.push_back((uint8_t)(n & 0xFF));
+        z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 0xFF));
+        z.push_back((uint8_t)((~n >> 8) & 0xFF));
+        z.insert(z.end(), raw.begin() + (long)pos, raw.begin() + (long)(pos + n));
+        pos += n;
+    } while (pos < raw.size());
+    uint32_t a = 1, b = 0; // Adler-32
+    for (uint8_t c : raw) {
+        a = (a + c) % 65521u;
+        b = (b + a) % 65521u;
+    }
+    put_be32(z, (b << 16) | a);
+
+    std::vector<uint8_t> png = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
+    std::vector<uint8_t> ihdr;
+    put_be32(ihdr, (uint32_t)width);
+    put_be32(ihdr, (uint32_t)height);
+    ihdr.push_back(8); // bit depth
+    ihdr.push_back(6); // RGBA
+    ihdr.push_back(0);
+    ihdr.push_back(0);
+    ihdr.push_back(0);
+    put_chunk(png, "IHDR", ihdr);
+    put_chunk(png, "IDAT", z);
+    put_chunk(png, "IEND", {});
+    return png;
+}
+
 uint8_t tonemap_channel(double c) { // examples/book-one.rs:95-97 (quirk Q13)
     const double v = std::fmin(std::sqrt(c) * 255.0, 255.0);
     if (!(v > 0.0)) return 0;

@@ -95,6 +95,10 @@ void camera_perspective(RtCameraD *out, const double eye[3], const double center
                         double aspect, double focus, double lens);
 
 uint8_t tonemap_channel(double c);
+// examples/main.rs:116-118: (c.sqrt() * 255.0).min(255.0) as u8  (Rust's float -> u8 cast saturates, NaN -> 0)
+uint8_t png_channel(double c);
+// 8-bit RGBA PNG file image (non-interlaced, filter 0, stored deflate blocks) of top-down RGBA rows
+std::vector<uint8_t> encode_png_rgba8(const uint8_t *rgba, int width, int height);
 
 } // namespace rt
 

@@ -11,7 +11,9 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <exception>
 #include <string>
+#include <thread>
 #include <typeinfo>
 #include <vector>
 
@@ -20,6 +22,7 @@ using namespace ray_tracer;
 
 struct Options {
     int width, height, spp, depth = 100, device = 0;
+    int gpus = 1; // one host thread + one committed copy of the scene per GPU, shards of 8x8 tiles dealt tile_id % gpus
     uint64_t seed = 1, scene_seed = 1;
     std::string out = "-";
     std::string checkpoint; // raw sums + progress, rewritten after every pass; an existing matching file is resumed
@@ -46,6 +49,7 @@ inline Options parse(int argc, char **argv, int w, int h, int spp) {
         else if (a == "--spp") o.spp = std::atoi(next());
         else if (a == "--depth") o.depth = std::atoi(next());
         else if (a == "--device") o.device = std::atoi(next());
+        else if (a == "--gpus") o.gpus = std::atoi(next());
         else if (a == "--seed") o.seed = std::strtoull(next(), nullptr, 10);
         else if (a == "--scene-seed") o.scene_seed = std::strtoull(next(), nullptr, 10);
         else if (a == "--out") o.out = next();
@@ -54,7 +58,7 @@ inline Options parse(int argc, char **argv, int w, int h, int spp) {
         else if (a == "--describe") o.describe = true;
         else {
             std::fprintf(stderr, "usage: %s [--width W] [--height H] [--spp N] [--depth D] [--seed S] [--scene-seed S] "
-                                 "[--device I] [--out file.ppm|-] [--passes N] [--checkpoint file] [--describe]\n", argv[0]);
+                                 "[--device I] [--gpus N] [--out file.ppm|file.png|-] [--passes N] [--checkpoint file] [--describe]\n", argv[0]);
             std::exit(2);
         }
     }
@@ -138,7 +142,38 @@ inline int run(const Options &o, const std::vector<SpritePtr> &sprites, const Pe
         return 1;
     }
     std::vector<Vec3> buffer;
-    if (o.passes <= 1 && o.checkpoint.empty()) {
+    if (o.gpus > 1) {
+        // The reference deals rows to host threads (examples/book-one.rs:56-65); here tiles are dealt to GPUs: every
+        // thread commits its own copy of the scene on "its" device and renders its shard straight into the shared
+        // image (the shards' pixels are disjoint, so there is nothing to merge and no collective).  Devices wrap
+        // around (--gpus 2 on a one-GPU box renders both shards on device 0), the image does not depend on N.
+        const int n_dev = rt_device_count();
+        if (n_dev < 1) {
+            std::fprintf(stderr, "no HIP device\n");
+            return 1;
+        }
+        if (o.passes > 1 || !o.checkpoint.empty()) {
+            std::fprintf(stderr, "--gpus cannot be combined with --passes / --checkpoint\n");
+            return 2;
+        }
+        std::vector<double> rgb((size_t)o.width * o.height * 3, 0.0);
+        std::vector<std::exception_ptr> errors((size_t)o.gpus);
+        std::vector<std::thread> threads;
+        for (int r = 0; r < o.gpus; ++r)
+            threads.emplace_back([&, r]() {
+                try {
+                    auto w = r == 0 ? world : BoundingVolumeHierarchyNode::make(sprites, (o.device + r) % n_dev);
+                    render_shard(*w, camera, o.width, o.height, o.spp, o.depth, o.seed, r, o.gpus, rgb.data());
+                } catch (...) {
+                    errors[(size_t)r] = std::current_exception();
+                }
+            });
+        for (std::thread &t : threads) t.join();
+        for (const std::exception_ptr &e : errors)
+            if (e) std::rethrow_exception(e);
+        buffer.resize((size_t)o.width * o.height);
+        for (size_t i = 0; i < buffer.size(); ++i) buffer[i] = Vec3(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]);
+    } else if (o.passes <= 1 && o.checkpoint.empty()) {
         buffer = render(*world, camera, o.width, o.height, o.spp, o.depth, o.seed);
     } else {
         // progressive: the reference's only progress report is main.rs printing finished rows to stderr
@@ -182,7 +217,11 @@ inline int run(const Options &o, const std::vector<SpritePtr> &sprites, const Pe
         const double n = (double)o.spp;
         for (size_t i = 0; i < buffer.size(); ++i) buffer[i] = Vec3(sums[i * 3] / n, sums[i * 3 + 1] / n, sums[i * 3 + 2] / n);
     }
-    write_ppm(o.out == "-" ? "/dev/stdout" : o.out, buffer, o.width, o.height); // P3 text like println! in the reference
+    const std::string path = o.out == "-" ? "/dev/stdout" : o.out;
+    if (path.size() > 4 && path.compare(path.size() - 4, 4, ".png") == 0)
+        write_png(path, buffer, o.width, o.height); // RGBA8 like examples/main.rs:105-135
+    else
+        write_ppm(path, buffer, o.width, o.height); // P3 text like println! in the reference
     return 0;
 }
 

@@ -278,6 +278,13 @@ inline std::vector<Vec3> render(const BoundingVolumeHierarchyNode &world, const 
     for (size_t i = 0; i < out.size(); ++i) out[i] = Vec3(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]);
     return out;
 }
+// One shard of render(): only the pixels of 8x8 tiles with tile_id % shard_count == shard_index are written into
+// rgb (width*height*3 doubles, y up) -- several worlds (one per GPU, one host thread each) can fill one image.
+inline void render_shard(const BoundingVolumeHierarchyNode &world, const PerspectiveCamera &camera, int width, int height,
+                         int subPixelSampleCount, int maxDepth, uint64_t seed, int shard_index, int shard_count, double *rgb) {
+    rt_render_params p{width, height, subPixelSampleCount, maxDepth, seed, shard_index, shard_count, 0u};
+    check(rt_render(world.raw(), &camera.c, &p, rgb, nullptr));
+}
 // Progressive form of render(): continues the raw per-pixel sums (width*height*3 doubles, y up) with samples
 // [s_begin, s_end) of the subPixelSampleCount-sample render; divide by subPixelSampleCount after the last
 // range.  Bit-identical to one render() call (rt_render_progressive).
@@ -295,6 +302,16 @@ inline void write_ppm(const std::string &path, const std::vector<Vec3> &buffer, 
         rgb[i * 3 + 2] = buffer[i].z;
     }
     check(rt_write_ppm_p3(path.c_str(), rgb.data(), width, height));
+}
+// examples/main.rs:105-135: RGBA8 PNG (the writer of the book-two cover driver)
+inline void write_png(const std::string &path, const std::vector<Vec3> &buffer, int width, int height) {
+    std::vector<double> rgb(buffer.size() * 3);
+    for (size_t i = 0; i < buffer.size(); ++i) {
+        rgb[i * 3] = buffer[i].x;
+        rgb[i * 3 + 1] = buffer[i].y;
+        rgb[i * 3 + 2] = buffer[i].z;
+    }
+    check(rt_write_png_rgba8(path.c_str(), rgb.data(), width, height));
 }
 
 } // namespace ray_tracer

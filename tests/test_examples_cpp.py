@@ -134,3 +134,34 @@ def test_cpp_driver_progressive_and_resume(binaries, gpu_device, tmp_path):
                        check=True, capture_output=True, text=True)
     assert "resuming" in r.stderr and "at 4 / 12 spp" in r.stderr
     assert res.read_bytes() == one.read_bytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exe,W,H,spp", [("book_one", 100, 60, 4), ("cover", 40, 40, 2)])
+def test_cpp_driver_gpus_flag_does_not_change_the_image(binaries, gpu_device, tmp_path, exe, W, H, spp):
+    """--gpus N: one host thread and one committed scene per GPU, tile shards written into one image (no collective).
+    On a one-GPU box the devices wrap around, so N = 2 and 3 rehearse the threading; the bytes must not depend on N."""
+    outs = []
+    for n in (1, 2, 3):
+        out = tmp_path / f"g{n}.ppm"
+        subprocess.run([str(binaries / exe), "--width", str(W), "--height", str(H), "--spp", str(spp), "--depth", "50", "--seed", "3",
+                        "--scene-seed", "2", "--gpus", str(n), "--out", str(out)], check=True)
+        outs.append(out.read_bytes())
+    assert outs[0] == outs[1] == outs[2]
+
+
+@pytest.mark.gpu
+def test_cpp_cover_driver_writes_the_reference_png(binaries, rt, scenes, gpu_device, tmp_path):
+    """--out x.png: the RGBA8 PNG path of examples/main.rs:105-135 (sqrt * 255, min 255, `as u8`, top-down rows)"""
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent / "golden"))
+    from make_cover_stats import read_png_rgb
+    W, H, spp = 48, 40, 3
+    out = tmp_path / "cover.png"
+    subprocess.run([str(binaries / "cover"), "--width", str(W), "--height", str(H), "--spp", str(spp), "--depth", "50", "--seed", "3",
+                    "--scene-seed", "2", "--out", str(out)], check=True)
+    sc, cam = scenes.build_product(scenes.cover(2, W / H), device=gpu_device)
+    img = sc.render(cam, W, H, spp, 50, seed=3)
+    got = read_png_rgb(out)
+    assert got.shape == (H, W, 3)
+    assert np.array_equal(got, rt.tonemap_png8(img)[::-1])

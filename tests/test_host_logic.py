@@ -230,3 +230,46 @@ def test_reference_limits_of_this_build(rt):
     with pytest.raises(rt.RtError) as e:
         s.commit(-1)
     assert e.value.code == -4
+
+
+def test_png_writer_restates_main_rs(rt, tmp_path):
+    """rt_write_png_rgba8 = examples/main.rs:105-135: channel (c.sqrt() * 255.0).min(255.0) as u8 (f64::min drops a
+    NaN, the cast truncates and saturates), alpha 255, put_pixel(x, height - 1 - y); decoded here with zlib alone."""
+    import struct
+    import sys
+    import zlib
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent / "golden"))
+    from make_cover_stats import read_png_rgb
+    rng = np.random.default_rng(0)
+    img = rng.uniform(0.0, 1.3, (37, 53, 3))
+    img[0, 0] = [np.nan, -1.0, np.inf]          # NaN / sqrt(-1) = NaN -> 255 (f64::min returns the other operand), inf -> 255
+    img[1, 1] = [-0.0, 0.0, 1.0]                # 0, 0, 255
+    img[2, 2] = [1e-300, 0.25, 0.999999]        # 0, 127 (127.5 truncates), 254
+    path = tmp_path / "t.png"
+    rt.write_png_rgba8(path, img)
+    with np.errstate(invalid="ignore"):
+        r = np.sqrt(img) * 255.0
+    want = np.where(np.isnan(r), 255.0, np.minimum(r, 255.0))
+    want = np.where(want <= 0.0, 0.0, want).astype(np.uint8)
+    assert np.array_equal(read_png_rgb(path), want[::-1])                      # rows top-down
+    assert np.array_equal(rt.tonemap_png8(img), want)
+    assert want[0, 0].tolist() == [255, 255, 255] and want[1, 1].tolist() == [0, 0, 255] and want[2, 2].tolist() == [0, 127, 254]
+    # container: signature, IHDR fields, per-chunk CRCs, zlib stream with a valid Adler-32 (zlib.decompress checks it)
+    b = path.read_bytes()
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, kinds = 8, []
+    while pos < len(b):
+        n, typ = struct.unpack(">I4s", b[pos:pos + 8])
+        data = b[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", b[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(typ + data)
+        if typ == b"IHDR":
+            assert struct.unpack(">IIBBBBB", data) == (53, 37, 8, 6, 0, 0, 0)
+        if typ == b"IDAT":
+            raw = zlib.decompress(data)
+            assert len(raw) == 37 * (1 + 53 * 4) and raw[4::4][:53] == b"\xff" * 53   # filter 0 rows, alpha 255
+        kinds.append(typ)
+        pos += 12 + n
+    assert kinds == [b"IHDR", b"IDAT", b"IEND"]
+    with pytest.raises(rt.RtError):
+        rt.write_png_rgba8(tmp_path / "no" / "dir.png", img)
