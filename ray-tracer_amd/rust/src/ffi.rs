@@ -70,4 +70,5 @@ extern "C" {
         counters: *mut std::ffi::c_void,
     ) -> c_int;
     pub fn rt_write_ppm_p3(path: *const c_char, rgb: *const c_double, w: c_int, h: c_int) -> c_int;
+    pub fn rt_write_png_rgba8(path: *const c_char, rgb: *const c_double, w: c_int, h: c_int) -> c_int; // examples/main.rs:105-135
 }

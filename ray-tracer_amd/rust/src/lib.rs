@@ -265,3 +265,11 @@ pub fn write_ppm(path: &str, buffer: &[Vec3], width: usize, height: usize) -> Re
     check(unsafe { ffi::rt_write_ppm_p3(c.as_ptr(), rgb.as_ptr(), width as i32, height as i32) })?;
     Ok(())
 }
+
+/// RGBA8 PNG exactly as examples/main.rs:105-135 builds it with the `image` crate
+pub fn write_png(path: &str, buffer: &[Vec3], width: usize, height: usize) -> Result<(), Error> {
+    let rgb: Vec<f64> = buffer.iter().flat_map(|v| vec![v.x, v.y, v.z]).collect();
+    let c = CString::new(path).unwrap();
+    check(unsafe { ffi::rt_write_png_rgba8(c.as_ptr(), rgb.as_ptr(), width as i32, height as i32) })?;
+    Ok(())
+}
