@@ -93,6 +93,13 @@ def main():
         res["regions"][name] = {"box": [x0, y0, x1, y1], "what": what, "tolerance_levels": tol,
                                 "mean": [round(v, 4) for v in r.mean(0)], "std": [round(v, 4) for v in r.std(0)],
                                 "min": [int(v) for v in r.min(0)], "max": [int(v) for v in r.max(0)]}
+    # geometry that does not depend on noise: the outline of the saturated light and the box around the orange sphere
+    lit = (im[:200] == 255).all(2)
+    res["light_outline"] = {"pixels": int(lit.sum()),
+                            "rows": {str(y): [int(np.where(lit[y])[0].min()), int(np.where(lit[y])[0].max())] for y in (0, 20, 60, 100, 118)}}
+    win = im[140:320, 60:240, 0] > 2
+    ys, xs = np.where(win)
+    res["orange_bbox"] = [int(xs.min()) + 60, int(ys.min()) + 140, int(xs.max()) + 60, int(ys.max()) + 140]
     DST.write_text(json.dumps(res, indent=1) + "\n")
     print("wrote", DST)
 

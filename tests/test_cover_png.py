@@ -8,7 +8,9 @@ HIP path (GPU) render this repo's restatement of the scene and must land on them
 
 Finding recorded by these tests: the picture was rendered WITHOUT the r = 5000 fog sprite that examples/main.rs
 now adds (its background is exactly 0 over 51,000 pixels x 1000 spp; with the fog the same pixels average ~55/255),
-so the comparison uses scenes.cover(with_fog=False); the fog's effect is asserted separately.
+so the comparison uses scenes.cover(with_fog=False); the fog's effect is asserted separately.  Its pixel noise is
+also ~0.66x that of a 1000 spp render here (high-pass std 4.5 vs 6.8 levels on the orange sphere), as if it had been
+rendered with about twice the samples of today's literal; means and outlines are what can be, and is, compared.
 """
 import json
 from pathlib import Path
@@ -16,16 +18,17 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-FIX = json.loads((Path(__file__).resolve().parent / "golden" / "cover_png_regions.json").read_text())["regions"]
+_ALL = json.loads((Path(__file__).resolve().parent / "golden" / "cover_png_regions.json").read_text())
+FIX = _ALL["regions"]
 W = H = 800
 SPP, DEPTH = 1000, 100
 
 
 def to8(c):
-    """examples/main.rs:113-121: (c.sqrt() * 255.0).min(255.0) as u8 (a NaN casts to 0)"""
+    """examples/main.rs:113-121: (c.sqrt() * 255.0).min(255.0) as u8 (f64::min drops a NaN: 255)"""
     with np.errstate(invalid="ignore"):
-        v = np.minimum(np.sqrt(c) * 255.0, 255.0)
-    return np.where(np.isnan(v), 0, v).astype(np.uint8)
+        v = np.sqrt(c) * 255.0
+    return np.where(np.isnan(v), 255.0, np.minimum(v, 255.0)).astype(np.uint8)
 
 
 def oracle_region(orc, name, spp, box=None):
@@ -88,6 +91,17 @@ def test_gpu_cover_matches_the_published_render(rt, scenes, gpu_device):
         assert img8[y0:y1, x0:x1].min() == img8[y0:y1, x0:x1].max() == FIX[name]["min"][0]
     # the sharpest one: a deterministic, smooth, noise-free region agrees to a fraction of a level
     assert np.all(np.abs(report["orange_core"] - np.array(FIX["orange_core"]["mean"])) <= 0.5), report["orange_core"]
+    # geometry, pixel for pixel: the outline of the saturated light (camera quirk Q1, the rotated rectangle's
+    # matrix pair) and the box around the orange sphere
+    lit = (img8[:200] == 255).all(2)
+    want = _ALL["light_outline"]
+    assert abs(int(lit.sum()) - want["pixels"]) <= 40, (int(lit.sum()), want["pixels"])      # 37,403 px: edge pixels only
+    for y, (a, b) in want["rows"].items():
+        xs = np.where(lit[int(y)])[0]
+        assert abs(int(xs.min()) - a) <= 1 and abs(int(xs.max()) - b) <= 1, (y, xs.min(), xs.max(), a, b)
+    ys, xs = np.where(img8[140:320, 60:240, 0] > 2)
+    box = [int(xs.min()) + 60, int(ys.min()) + 140, int(xs.max()) + 60, int(ys.max()) + 140]
+    assert all(abs(g - w) <= 1 for g, w in zip(box, _ALL["orange_bbox"])), (box, _ALL["orange_bbox"])
 
 
 @pytest.mark.gpu
