@@ -209,7 +209,7 @@ def main():
                          "simd_utilisation": {b: cnt[b + "_lane"] / max(1, 64 * cnt[b + "_wave"]) for b in ("node", "leaf", "shade")},
                          "block_executions_per_sample": {b: cnt[b + "_wave"] * 64 / ns for b in ("node", "leaf", "shade")},
                          "block_cycle_share": {b: cnt[b + "_cycles"] / max(1, cnt["node_cycles"] + cnt["leaf_cycles"] + cnt["shade_cycles"])
-                                               for b in ("node", "leaf", "shade", "finish", "refill", "begin")},
+                                               for b in ("node", "leaf", "shade", "finish", "refill", "begin", "swap")},
                          "swap_at_shade": ({k[5:]: cnt[k] for k in cnt if k.startswith("swap_")} if cnt.get("swap_scattered") else None)},
             "wall_s": dt, "last_kernel_ms": last_kernel_ms,
         }

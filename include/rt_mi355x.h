@@ -153,6 +153,7 @@ typedef struct rt_counters {
      * parked in and pulled from the workgroup queues, queue locks found busy, paths scattered, and of those the
      * ones scattered outside the chosen class (could not be parked) */
     uint64_t swap_class_mode, swap_new_mode, swap_parked, swap_pulled, swap_lock_busy, swap_scattered, swap_off_class;
+    uint64_t swap_cycles; /* of finish_cycles: classification + queue traffic of the swap (counting build) */
 } rt_counters;
 
 /* Render into host memory: out_rgb[(y*W + x)*3 + c].  With shard_count > 1 only

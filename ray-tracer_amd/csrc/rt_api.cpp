@@ -539,6 +539,7 @@ int rt_render(rt_scene *s, const rt_camera *cam, const rt_render_params *p, doub
             counters->swap_lock_busy = c.swap_lock_busy;
             counters->swap_scattered = c.swap_scattered;
             counters->swap_off_class = c.swap_off_class;
+            counters->swap_cycles = c.swap_cycles;
         }
     }
     (void)hipFree(d_out);

@@ -587,6 +587,11 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
         fs.root = RT_CUR_DONE;
         fs.max_depth = 0;
     }
+    // the material's kind rides in the prim's meta word (RtPrimMeta::kind bits 8-15)
+    for (RtPrimMeta &m : fs.prim_meta) {
+        const uint32_t mk = m.material == RT_NO_MATERIAL ? (uint32_t)RT_MAT_KIND_NONE : fs.materials[m.material].kind;
+        m.kind = (m.kind & 0xFFu) | (mk << 8);
+    }
     *out = std::move(fs);
     return RT_OK;
 }

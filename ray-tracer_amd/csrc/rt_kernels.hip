@@ -151,7 +151,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
     st.base = stack_mem + threadIdx.x;
     const RtNode *nodes = L.nodes;
     const unsigned node_lds_bytes = LDSNODES ? (unsigned)L.n_nodes * (unsigned)sizeof(RtNode) : 0u;
-    // swap queues: header {count[3], pad, lock[3], pad}, then per class RT_SWAP_F64 arrays of CAP doubles and
+    // swap queues: header {state[3], pad...}: state = entries in the queue | kSwapLock while a wave works on it; then per class RT_SWAP_F64 arrays of CAP doubles and
     // RT_SWAP_F32 arrays of CAP words (field-major: consecutive entries are consecutive addresses)
     unsigned char *swap_mem = rt_lds + (size_t)L.stack_entries * kBlock * sizeof(uint32_t) + node_lds_bytes;
     uint32_t *swap_hdr = reinterpret_cast<uint32_t *>(swap_mem);
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
     unsigned long long c_nodes = 0, c_prims = 0, c_segs = 0, c_draws = 0, c_samples = 0;
     unsigned long long c_nw = 0, c_nl = 0, c_lw = 0, c_ll = 0, c_sw = 0, c_sl = 0;
     unsigned long long t_n = 0, t_l = 0, t_s = 0, t_fin = 0, t_ref = 0, t_beg = 0, t0 = 0, t1 = 0;
-    unsigned long long w_class = 0, w_new = 0, w_park = 0, w_pull = 0, w_busy = 0, w_scat = 0, w_off = 0; // swap diagnostics
+    unsigned long long w_class = 0, w_new = 0, w_park = 0, w_pull = 0, w_busy = 0, w_scat = 0, w_off = 0, t_swap = 0; // swap diagnostics
 #define RT_STAMP(v) do { if (COUNT) v = __builtin_amdgcn_s_memtime(); } while (0)
     const bool counting_lane = COUNT && (threadIdx.x & 63) == 0;
 
@@ -222,9 +222,12 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                 uint32_t cls = kNone;
                 if ((is_done && !has_path) || tv.cur == RT_CUR_DEAD) cls = kEmpty;
                 if (is_done && has_path) {
-                    uint32_t mat = RT_NO_MATERIAL, kind = 0xFFu;
-                    if (tv.best_prim != 0xFFFFFFFFu) mat = L.prim_meta[tv.best_prim].material;
-                    if (mat != RT_NO_MATERIAL) kind = L.materials[mat].kind;
+                    uint32_t mat = RT_NO_MATERIAL, kind = RT_MAT_KIND_NONE;
+                    if (tv.best_prim != 0xFFFFFFFFu) { // one 8-byte load: the material's kind rides in the meta word
+                        const uint2 pm = *reinterpret_cast<const uint2 *>(&L.prim_meta[tv.best_prim]);
+                        kind = (pm.x >> 8) & 0xFFu;
+                        mat = pm.y;
+                    }
                     if (kind < (uint32_t)RT_SWAP_CLASSES) {
                         cls = kind;
                     } else if (kind == RT_MAT_ISOTROPIC || (TEXTURED && kind == RT_MAT_DIFFUSE_LIGHT)) {
@@ -247,9 +250,10 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                 // 2. mode: the class with the most lanes (own + parked), or "new samples" when no class fills the wave
                 const unsigned long long m0 = __ballot(cls == 0u), m1 = __ballot(cls == 1u), m2 = __ballot(cls == 2u);
                 const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2);
-                const uint32_t q0 = __hip_atomic_load(&swap_hdr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const uint32_t q1 = __hip_atomic_load(&swap_hdr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const uint32_t q2 = __hip_atomic_load(&swap_hdr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                constexpr uint32_t kSwapLock = 0x80000000u;
+                const uint32_t q0 = __hip_atomic_load(&swap_hdr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & ~kSwapLock;
+                const uint32_t q1 = __hip_atomic_load(&swap_hdr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & ~kSwapLock;
+                const uint32_t q2 = __hip_atomic_load(&swap_hdr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & ~kSwapLock;
                 // a class is eligible when it can (nearly) fill the wave; among the eligible ones the fullest queue goes
                 // first, so the rare classes (metal, glass) are drained in whole waves instead of clogging their queue
                 const uint32_t t0s = n0 + q0, t1s = n1 + q1, t2s = n2 + q2;
@@ -292,15 +296,18 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                     const bool push_c = allow_push && (mode_new || lane != cstar) && my_n > 0u && my_q < (uint32_t)RT_SWAP_CAP;
                     const bool pull_c = !mode_new && lane == cstar && my_q > 0u;
                     if (push_c || pull_c) {
-                        // bounded retry: a holder never waits for anything, so the lock frees within a few hundred cycles
+                        // One compare-and-swap both takes the lock and learns the exact count: count -> count | lock.
+                        // A failed attempt returns the current word: locked -> back off, then try with that count;
+                        // bounded: a holder never waits for anything, so the lock frees within a few hundred cycles.
+                        uint32_t expected = my_q;
                         for (int attempt = 0; attempt < RT_SWAP_LOCK_TRIES && got == 0u; ++attempt) {
-                            uint32_t expected = 0u;
-                            if (__hip_atomic_compare_exchange_strong(&swap_hdr[4u + lane], &expected, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
-                                                                     __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                            if (__hip_atomic_compare_exchange_strong(&swap_hdr[lane], &expected, expected | kSwapLock, __ATOMIC_ACQUIRE,
+                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
                                 got = 1u;
-                                cnt = __hip_atomic_load(&swap_hdr[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                cnt = expected;
                             } else {
-                                __builtin_amdgcn_s_sleep(2);
+                                if (expected & kSwapLock) __builtin_amdgcn_s_sleep(2);
+                                expected &= ~kSwapLock;
                             }
                         }
                         if (COUNT && got == 0u) ++w_busy;
@@ -382,8 +389,11 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                         now = cnt - pulled;
                     else
                         now = cnt + min(my_n, (uint32_t)RT_SWAP_CAP - cnt);
-                    __hip_atomic_store(&swap_hdr[lane], now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_store(&swap_hdr[4u + lane], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&swap_hdr[lane], now, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); // count without the lock bit
+                }
+                if (COUNT) { // cycles of classification + queue traffic (steps 1-6), part of finish_cycles
+                    const unsigned long long t_mid = __builtin_amdgcn_s_memtime();
+                    t_swap += t_mid - t0;
                 }
                 // 7. scatter what is in registers now: the chosen class, plus whatever could not be parked
                 if (COUNT && counting_lane) {
@@ -534,6 +544,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
             atomicAdd(&L.counters->swap_lock_busy, w_busy);
             atomicAdd(&L.counters->swap_scattered, w_scat);
             atomicAdd(&L.counters->swap_off_class, w_off);
+            if (counting_lane) atomicAdd(&L.counters->swap_cycles, t_swap);
         }
         if (counting_lane) {
             atomicAdd(&L.counters->node_wave, c_nw);

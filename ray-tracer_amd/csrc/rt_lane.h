@@ -263,7 +263,7 @@ RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx
     const RtPrimGeo &G = L.prim_geo[pi];
     r->sub = 0u;
     uint32_t kind = (uint32_t)RT_PRIM_SPHERE_T;
-    if (GENERAL || MEDIUM) kind = L.prim_meta[pi].kind;
+    if (GENERAL || MEDIUM) kind = L.prim_meta[pi].kind & 0xFFu; // bits 8-15 carry the material's kind
     ++sc.prims_tested;
     if (kind == RT_PRIM_SPHERE_T) {
         // Sprite::hit with a translation matrix: M^-1 (o,1) = o - c, M^-1 (d,0) = d,

@@ -12,6 +12,7 @@
 #define RT_MAX_HOISTED 4    /* scene-spanning prims tested up front instead of through the BVH */
 #define RT_JOB_SPP_MAX 32   /* samples per pixel in one job at most (job = one 8x8 tile x job_spp samples) */
 #define RT_NO_MATERIAL 0xFFFFFFFFu
+#define RT_MAT_KIND_NONE 0xFFu /* in RtPrimMeta::kind bits 8-15: the prim has no material */
 
 // 16-bit child references (stack entries pack one next to a truncated f32 tnear)
 #define RT_REF_LEAF 0x8000u       /* bit 15: leaf, low 15 bits = prim index; else inner node index */
@@ -50,7 +51,8 @@ struct alignas(16) RtNode {
 }; // 64 B
 
 struct alignas(16) RtPrimMeta {
-    uint32_t kind;
+    uint32_t kind;     // bits 0-7: RT_PRIM_*; bits 8-15: kind of its material (RT_MAT_*, RT_MAT_KIND_NONE without one), so
+                       // the shade block classifies a hit with one load
     uint32_t material; // RT_NO_MATERIAL = the reference's `material: None`
     uint32_t xform;    // index into xforms (kinds *_M)
     uint32_t aux;      // GROUP: first child prim; MEDIUM: rng slot
@@ -101,7 +103,7 @@ struct RtCounters {
     // s_memtime cycles spent inside each block, summed over waves (counting build only)
     unsigned long long node_cycles, leaf_cycles, shade_cycles, finish_cycles, refill_cycles, begin_cycles;
     // swap-at-shade diagnostics (see include/rt_mi355x.h)
-    unsigned long long swap_class_mode, swap_new_mode, swap_parked, swap_pulled, swap_lock_busy, swap_scattered, swap_off_class;
+    unsigned long long swap_class_mode, swap_new_mode, swap_parked, swap_pulled, swap_lock_busy, swap_scattered, swap_off_class, swap_cycles;
 };
 
 // kernel arguments (passed by value)
