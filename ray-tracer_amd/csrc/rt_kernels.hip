@@ -98,6 +98,15 @@
 #ifndef RT_SWAP_REFILL_MIN
 #define RT_SWAP_REFILL_MIN 65 /* empty lanes that force a refill even in a class mode */
 #endif
+#ifndef RT_SWAP_EARLY_RELEASE
+#define RT_SWAP_EARLY_RELEASE 1
+#endif
+#ifndef RT_SWAP_SLEEP
+#define RT_SWAP_SLEEP 2 /* s_sleep argument (x 64 clocks) while a queue lock is held by another wave */
+#endif
+#ifndef RT_SWAP_PROBE
+#define RT_SWAP_PROBE 6 /* diagnostics: swap_cycles covers steps 1..RT_SWAP_PROBE of the swap (6 = all of it) */
+#endif
 #ifndef RT_SWAP_POLICY
 #define RT_SWAP_POLICY 0 /* 0: the class with most lanes (own + parked); 1: the eligible class with the fullest queue */
 #endif
@@ -247,6 +256,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                         }
                     }
                 }
+                if (COUNT && RT_SWAP_PROBE == 1) t_swap += __builtin_amdgcn_s_memtime() - t0;
                 // 2. mode: the class with the most lanes (own + parked), or "new samples" when no class fills the wave
                 const unsigned long long m0 = __ballot(cls == 0u), m1 = __ballot(cls == 1u), m2 = __ballot(cls == 2u);
                 const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2);
@@ -288,6 +298,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                 }
                 const bool mode_new = !queue_empty && !eligible;
                 const bool allow_push = !queue_empty; // once the job queue is dry the wave only drains
+                if (COUNT && RT_SWAP_PROBE == 2) t_swap += __builtin_amdgcn_s_memtime() - t0;
                 // 3. lanes 0..2 try the lock of "their" class (never wait: a busy queue is skipped this time)
                 uint32_t got = 0u, cnt = 0u, my_n = 0u;
                 if (lane < (uint32_t)RT_SWAP_CLASSES) {
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                                 got = 1u;
                                 cnt = expected;
                             } else {
-                                if (expected & kSwapLock) __builtin_amdgcn_s_sleep(2);
+                                if (expected & kSwapLock) __builtin_amdgcn_s_sleep(RT_SWAP_SLEEP);
                                 expected &= ~kSwapLock;
                             }
                         }
@@ -317,6 +328,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                                g2 = (uint32_t)__builtin_amdgcn_readlane((int)got, 2);
                 const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)cnt, 0), k1 = (uint32_t)__builtin_amdgcn_readlane((int)cnt, 1),
                                k2 = (uint32_t)__builtin_amdgcn_readlane((int)cnt, 2);
+                if (COUNT && RT_SWAP_PROBE == 3) t_swap += __builtin_amdgcn_s_memtime() - t0;
                 unsigned char *qbase = swap_mem + RT_SWAP_HDR_BYTES;
                 // 4. park the lanes of the other classes (every class in "new" mode)
                 if (cls < (uint32_t)RT_SWAP_CLASSES && allow_push && (mode_new || cls != cstar)) {
@@ -349,6 +361,14 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                         if (COUNT) ++w_park;
                     }
                 }
+                // the parked classes are done: publish their counts and free their locks before the pull (shorter hold time)
+                bool released = false;
+                if (RT_SWAP_EARLY_RELEASE && got != 0u && (mode_new || lane != cstar)) {
+                    __hip_atomic_store(&swap_hdr[lane], cnt + min(my_n, (uint32_t)RT_SWAP_CAP - cnt), __ATOMIC_RELEASE,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                    released = true;
+                }
+                if (COUNT && RT_SWAP_PROBE == 4) t_swap += __builtin_amdgcn_s_memtime() - t0;
                 // 5. pull parked paths of the chosen class into the free lanes (newest first)
                 uint32_t pulled = 0u;
                 {
@@ -382,8 +402,9 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                         }
                     }
                 }
+                if (COUNT && RT_SWAP_PROBE == 5) t_swap += __builtin_amdgcn_s_memtime() - t0;
                 // 6. publish the new counts and release (the release orders this wave's queue traffic before it)
-                if (got != 0u) {
+                if (got != 0u && !released) {
                     uint32_t now = cnt;
                     if (!mode_new && lane == cstar)
                         now = cnt - pulled;
@@ -391,10 +412,8 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                         now = cnt + min(my_n, (uint32_t)RT_SWAP_CAP - cnt);
                     __hip_atomic_store(&swap_hdr[lane], now, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); // count without the lock bit
                 }
-                if (COUNT) { // cycles of classification + queue traffic (steps 1-6), part of finish_cycles
-                    const unsigned long long t_mid = __builtin_amdgcn_s_memtime();
-                    t_swap += t_mid - t0;
-                }
+                if (COUNT && RT_SWAP_PROBE == 6) // cycles of classification + queue traffic (steps 1-6), part of finish_cycles
+                    t_swap += __builtin_amdgcn_s_memtime() - t0;
                 // 7. scatter what is in registers now: the chosen class, plus whatever could not be parked
                 if (COUNT && counting_lane) {
                     if (mode_new) ++w_new; else ++w_class;
