@@ -10,10 +10,13 @@
 //                    descent, LDS stack push/pop with tnear culling;
 //     leaf block  -- the binary64 primitive test (the reference's arithmetic);
 //     shade block -- binary64 hit record + Material::scatter, then the next
-//                    segment; a finished path stores its radiance and the lane
-//                    immediately takes the next sample of the wave's job queue
-//                    (jobs = 8x8-pixel tile x job_spp samples, drawn from one
-//                    device-wide atomic counter).
+//                    segment; a finished path stores its radiance.  Finished lanes
+//                    of one wave hold a mix of materials, so the wave first swaps
+//                    paths with the other waves of its workgroup through per-class
+//                    queues in LDS ("swap at shade", below): it scatters one
+//                    material class at a time, or starts new samples for the whole
+//                    wave at once (jobs = 8x8-pixel tile x job_spp samples, drawn
+//                    from one device-wide atomic counter).
 //   The expensive blocks only run when enough lanes have queued up for them (or
 //   nothing else can run), so each block executes at high SIMD occupancy instead
 //   of every lane dragging the other 63 through its own branch.  Lanes never idle
@@ -21,6 +24,10 @@
 //   is empty.  Scheduling never changes a result: each path consumes its own
 //   random stream (include/rt_rng.h) and every sample is an independent value.
 //   The traversal stack lives in LDS, [depth][thread], conflict-free ds_read/write_b32.
+//   Three kernel families share the code: spheres only (book-one: 125 VGPRs, 4 waves
+//   per SIMD, 512-thread groups), general prims without media / textures (Cornell box:
+//   157 VGPRs, 3 waves per SIMD as three 256-thread groups per CU) and the full general
+//   kernel (245 VGPRs, 2 waves per SIMD).
 //
 // reduce_kernel -- pixel = (((s_0 + s_1) + s_2) + ...) / spp in sample order, the
 //   rounding of `pixel += color(...)` in examples/book-one.rs:69-76.  Per-sample
