@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""GPU box, one-off: many random general scenes (tests/test_random_scenes.py: non-rigid matrices, cubes, media,
+textures, lens) through the C ABI against the oracle's iterative form.  -> gpurun_out/random_parity.json"""
+import importlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+from __graft_entry__ import load_package  # noqa: E402
+
+rt = load_package()
+scenes = importlib.import_module("ray_tracer_amd.scenes")
+import oracle_binding as oracle  # noqa: E402
+from test_random_scenes import random_scene  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+threads = min(256, os.cpu_count() or 8)
+t0 = time.time()
+worst_mae, worst_max, exact, bad_pixels, pixels = 0.0, 0.0, 0, 0, 0
+hist = {}
+for seed in range(100, 100 + N):
+    d = random_scene(scenes, seed)
+    rng = np.random.default_rng(seed)
+    W, H, spp = int(rng.integers(24, 96)), int(rng.integers(16, 72)), int(rng.integers(2, 12))
+    sc, cam = scenes.build_product(d, device=0)
+    img = sc.render(cam, W, H, spp, 40, seed=seed)
+    ref = oracle.build_oracle(d, bvh_seed=seed).render(W, H, spp, 40, seed=seed, iterative=True, nthreads=threads)
+    diff = np.abs(img - ref)
+    finite = np.isfinite(ref).all() and np.isfinite(img).all()
+    mae = float(diff.mean()) if finite else float("nan")
+    nbad = int((diff.max(axis=2) > 1e-12).sum())
+    worst_mae = max(worst_mae, mae)
+    worst_max = max(worst_max, float(diff.max()))
+    exact += int(np.array_equal(img, ref))
+    bad_pixels += nbad
+    pixels += W * H
+    hist[nbad] = hist.get(nbad, 0) + 1
+    if not finite or mae > 1e-4:
+        print("FAIL seed", seed, W, H, spp, mae, nbad, flush=True)
+        sys.exit(1)
+res = {"scenes": N, "bit_identical_scenes": exact, "pixels": pixels, "pixels_differing_by_more_than_1e-12": bad_pixels,
+       "worst_mean_abs_error": worst_mae, "worst_abs_diff": worst_max, "differing_pixels_per_scene_histogram": {str(k): v for k, v in sorted(hist.items())},
+       "seconds": time.time() - t0, "bar": "mean abs error <= 1e-4 per scene"}
+print(res)
+json.dump(res, open(ROOT / "gpurun_out" / "random_parity.json", "w"), indent=1)
