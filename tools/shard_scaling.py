@@ -19,7 +19,7 @@ sc, cam = scenes.build_product(scenes.book_one(1, W / H), device=0)
 dev = torch.device("cuda", 0)
 base = None
 for n in (1, 2, 4, 8):
-    worst = 0.0
+    worst, worst_kern, kern = 0.0, 0.0, 0.0
     for r in (0, n - 1):
         cnt = rt.shard_tile_count(W, H, r, n)
         buf = torch.zeros(cnt * 64 * 3, dtype=torch.float64, device=dev)
@@ -30,7 +30,11 @@ for n in (1, 2, 4, 8):
             t0 = time.perf_counter()
             sc.render_tiles_device(cam, W, H, spp, depth, 1, (r, n), buf.data_ptr(), None, st)
             torch.cuda.synchronize()
-            best = min(best, time.perf_counter() - t0)
-        worst = max(worst, best)
+            dt = time.perf_counter() - t0
+            if dt < best:
+                best, kern = dt, sc.last_kernel_ms()
+        if best > worst:
+            worst, worst_kern = best, kern
     base = base or worst
-    print(f"N={n}: slowest shard {worst * 1e3:.2f} ms  -> ideal-gather speedup {base / worst:.2f}x", flush=True)
+    print(f"N={n}: slowest shard {worst * 1e3:.2f} ms (render_kernel {worst_kern:.2f} ms, ideal {base * 1e3 / n:.2f} ms)"
+          f"  -> ideal-gather speedup {base / worst:.2f}x", flush=True)
