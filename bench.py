@@ -46,6 +46,8 @@ def parse():
                     help="gloo = rehearsal of the N>1 path on a box with fewer GPUs (shards staged through host memory)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--check", action="store_true", help="rank 0 also renders the whole image alone and compares")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="experiment: consecutive steps on two alternating streams (measured slower, see DESIGN.md section 8)")
     return ap.parse_args()
 
 
@@ -107,8 +109,14 @@ def main():
 
     n_tiles = [rt.shard_tile_count(W, H, r, world) for r in range(world)]
     pad_tiles = max(n_tiles)
-    mine = torch.zeros(pad_tiles * 64 * 3, dtype=torch.float64, device=dev)
-    gathered = torch.zeros(world * pad_tiles * 64 * 3, dtype=torch.float64, device=dev) if rank == 0 else None
+    # --pipeline: two of everything a step writes and consecutive steps on alternating streams, so that the render of
+    # step k+1 could fill the CUs while step k's last few 100-segment paths, its reduce, gather and unpack finish (the
+    # library keeps two render slots per scene).  Measured SLOWER than one stream on the MI355X, so it is off by default
+    n_buf = 2 if a.pipeline else 1
+    mines = [torch.zeros(pad_tiles * 64 * 3, dtype=torch.float64, device=dev) for _ in range(n_buf)]
+    gathereds = [torch.zeros(world * pad_tiles * 64 * 3, dtype=torch.float64, device=dev) if rank == 0 else None for _ in range(n_buf)]
+    render_streams = [torch.cuda.Stream(device=dev) for _ in range(n_buf)]
+    mine = mines[0]
     # rank 0: double-buffered image + a copy stream, so the device->host copy of step k overlaps the render of
     # step k+1 (every copy still completes inside the timed region: sync() waits for all streams)
     images = [torch.zeros(H * W * 3, dtype=torch.float64, device=dev) for _ in range(2)] if rank == 0 else None
@@ -118,29 +126,33 @@ def main():
     step_no = [0]
 
     def step():
-        stream = torch.cuda.current_stream().cuda_stream
-        sc.render_tiles_device(cam, W, H, spp, depth, a.seed, (rank, world), mine.data_ptr(), None, stream)
-        if world > 1 and a.backend == "nccl":
-            glist = list(gathered.chunk(world)) if rank == 0 else None
-            dist.gather(mine, glist, dst=0)  # the one collective of the path (RCCL over xGMI)
-        elif world > 1:
-            hm = mine.cpu()
-            hl = [torch.zeros_like(hm) for _ in range(world)] if rank == 0 else None
-            dist.gather(hm, hl, dst=0)
+        k = step_no[0]
+        step_no[0] += 1
+        rs = render_streams[k % n_buf]
+        mine_k, gathered_k = mines[k % n_buf], gathereds[k % n_buf]
+        with torch.cuda.stream(rs):
+            stream = rs.cuda_stream
+            sc.render_tiles_device(cam, W, H, spp, depth, a.seed, (rank, world), mine_k.data_ptr(), None, stream)
+            if world > 1 and a.backend == "nccl":
+                glist = list(gathered_k.chunk(world)) if rank == 0 else None
+                dist.gather(mine_k, glist, dst=0)  # the one collective of the path (RCCL over xGMI)
+            elif world > 1:
+                hm = mine_k.cpu()
+                hl = [torch.zeros_like(hm) for _ in range(world)] if rank == 0 else None
+                dist.gather(hm, hl, dst=0)
+                if rank == 0:
+                    gathered_k.copy_(torch.cat(hl))
             if rank == 0:
-                gathered.copy_(torch.cat(hl))
-        if rank == 0:
-            b = step_no[0] & 1
-            step_no[0] += 1
-            src = gathered if world > 1 else mine
-            torch.cuda.current_stream().wait_event(copy_done[b])  # the copy that last read images[b] has finished
-            rt.unpack_tiles_device(src.data_ptr(), pad_tiles, world, W, H, images[b].data_ptr(), stream)
-            unpacked = torch.cuda.Event()
-            unpacked.record()
-            copy_stream.wait_event(unpacked)
-            with torch.cuda.stream(copy_stream):
-                host_images[b].copy_(images[b], non_blocking=True)
-                copy_done[b].record()
+                b = k & 1
+                src = gathered_k if world > 1 else mine_k
+                rs.wait_event(copy_done[b])  # the copy that last read images[b] has finished
+                rt.unpack_tiles_device(src.data_ptr(), pad_tiles, world, W, H, images[b].data_ptr(), stream)
+                unpacked = torch.cuda.Event()
+                unpacked.record(rs)
+                copy_stream.wait_event(unpacked)
+                with torch.cuda.stream(copy_stream):
+                    host_images[b].copy_(images[b], non_blocking=True)
+                    copy_done[b].record(copy_stream)
 
     def sync():
         if world > 1:
@@ -199,7 +211,8 @@ def main():
             "config": {"workload": (f"book-one random-spheres {W}x{H}, {spp} spp, depth {depth} (BASELINE.json configs[1])"
                                     if a.scene == "book_one" else f"{a.scene} {W}x{H}, {spp} spp, depth {depth}"),
                        "scene_seed": a.scene_seed, "render_seed": a.seed, "n_spheres": info["n_prims"],
-                       "bvh_nodes": info["n_nodes"], "sharding": f"8x8 tiles, tile_id % {world}, one RCCL gather"},
+                       "bvh_nodes": info["n_nodes"], "sharding": f"8x8 tiles, tile_id % {world}, one RCCL gather",
+                       "steps_pipelined_on_two_streams": bool(a.pipeline)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu_pmc": valu,
                          "note": "algorithmic bytes are served from LDS/L1/L2 (scene < 100 KB): the kernel is VALU-issue bound, see DESIGN.md",

@@ -172,7 +172,10 @@ int rt_render_progressive(rt_scene *, const rt_camera *, const rt_render_params 
  * d_tiles_out receives this shard's tiles PACKED in ascending tile id:
  * [k][py][px][3] doubles, k-th owned tile, RT_TILE*RT_TILE pixels each.
  * Asynchronous: returns after enqueueing.  rt_shard_tile_count gives the number
- * of tiles (buffer size = count * 64 * 3 doubles). */
+ * of tiles (buffer size = count * 64 * 3 doubles).
+ * A scene keeps two render slots (sample workspace, job counter, timing events): two calls on different streams run
+ * concurrently on the device -- the second one's workgroups fill the CUs while the first one's last long paths, its
+ * reduce and whatever the caller enqueued behind it finish; a third call is ordered behind the slot it reuses. */
 int rt_shard_tile_count(int width, int height, int shard_index, int shard_count);
 int rt_render_tiles_device(rt_scene *, const rt_camera *, const rt_render_params *, void *d_tiles_out, void *d_counters,
                            void *stream);

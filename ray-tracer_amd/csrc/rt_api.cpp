@@ -199,7 +199,6 @@ int rt_scene_commit(rt_scene *s, int device) {
         if ((rc = upload(s->flat.textures, &s->d_textures, &total))) return rc;
         if ((rc = upload(s->flat.image_blob, &s->d_blob, &total))) return rc;
         s->device_bytes = total;
-        HIP_TRY(hipMalloc(&s->d_job_counter, 256));
     }
     s->committed = true;
     return RT_OK;
@@ -274,7 +273,7 @@ static void fill_launch(const rt_scene *s, const rt_camera *cam, const rt_render
     L->shard_index = p->shard_index;
     L->shard_count = p->shard_count;
     L->n_owned_tiles = n_owned;
-    L->job_counter = (unsigned int *)s->d_job_counter;
+    L->job_counter = nullptr; // set per render slot
 }
 
 static unsigned kernel_features(const rt_scene *s) {
@@ -304,7 +303,12 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     if (n_owned < 0) return n_owned;
     hipStream_t st = (hipStream_t)stream;
     std::lock_guard<std::mutex> lock(s->mu);
-    s->events_used = 0;
+    // slot 0 unless its last render is still running (then the two renders overlap on the device)
+    int slot_index = 0;
+    if (s->slots[0].used && hipEventQuery(s->slots[0].done) == hipErrorNotReady) slot_index = s->last_slot == 0 ? 1 : 0;
+    rt_scene::RenderSlot &sl = s->slots[slot_index];
+    s->last_slot = slot_index;
+    sl.events_used = 0;
     s->timed = true;
     if (n_owned == 0) return RT_OK;
     const size_t tile_doubles = (size_t)n_owned * RT_TILE_PIXELS * 3;
@@ -321,15 +325,18 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     chunk = (int)std::min<size_t>((size_t)chunk, (size_t)0xFFFFFFFFu / ((size_t)n_owned * RT_TILE_PIXELS));
     if (chunk < 1) return fail(RT_ERR_INVALID, "image too large for one shard");
     const size_t need = bytes_per_spp * (size_t)chunk;
-    if (need > s->samples_bytes) {
-        if (s->d_samples) {
+    if (!sl.done) HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    if (!sl.d_job_counter) HIP_TRY(hipMalloc(&sl.d_job_counter, 256));
+    if (sl.used) HIP_TRY(hipStreamWaitEvent(st, sl.done, 0)); // the slot's previous render (any stream) has to be through
+    if (need > sl.samples_bytes) {
+        if (sl.d_samples) {
             HIP_TRY(hipDeviceSynchronize()); // an earlier render (any stream) may still read the old workspace
-            HIP_TRY(hipFree(s->d_samples));
-            s->d_samples = nullptr;
-            s->samples_bytes = 0;
+            HIP_TRY(hipFree(sl.d_samples));
+            sl.d_samples = nullptr;
+            sl.samples_bytes = 0;
         }
-        HIP_TRY(hipMalloc(&s->d_samples, need));
-        s->samples_bytes = need;
+        HIP_TRY(hipMalloc(&sl.d_samples, need));
+        sl.samples_bytes = need;
     }
     const bool count = (p->flags & RT_FLAG_COUNTERS) && d_counters;
     const unsigned feat = kernel_features(s);
@@ -366,13 +373,14 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
         s->occ_per_cu = per_cu;
         s->occ_n_cu = n_cu;
     }
-    L.samples = (double *)s->d_samples;
+    L.samples = (double *)sl.d_samples;
+    L.job_counter = (unsigned int *)sl.d_job_counter;
     L.counters = count ? (RtCounters *)d_counters : nullptr;
     const int n_pass = (n_spp + chunk - 1) / chunk;
-    while ((int)s->events.size() < 2 * n_pass) {
+    while ((int)sl.events.size() < 2 * n_pass) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
-        s->events.push_back(e);
+        sl.events.push_back(e);
     }
     for (int pass = 0; pass < n_pass; ++pass) {
         L.s0 = s_begin + pass * chunk;
@@ -392,17 +400,19 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
         const long long waves_per_block = block / 64;
         const long long want = (n_jobs + waves_per_block - 1) / waves_per_block;
         const int blocks = (int)std::min<long long>((long long)per_cu * n_cu, want > 0 ? want : 1);
-        HIP_TRY(hipMemsetAsync(s->d_job_counter, 0, sizeof(unsigned int), st));
-        HIP_TRY(hipEventRecord(s->events[(size_t)(2 * pass)], st));
+        HIP_TRY(hipMemsetAsync(sl.d_job_counter, 0, sizeof(unsigned int), st));
+        HIP_TRY(hipEventRecord(sl.events[(size_t)(2 * pass)], st));
         rc = rt_launch_render(&L, feat, lens, count, lds_mode, blocks, lds_bytes, stream);
         if (rc != 0) return hip_fail((hipError_t)rc, "render_kernel launch");
-        HIP_TRY(hipEventRecord(s->events[(size_t)(2 * pass + 1)], st));
-        s->events_used = 2 * (pass + 1);
+        HIP_TRY(hipEventRecord(sl.events[(size_t)(2 * pass + 1)], st));
+        sl.events_used = 2 * (pass + 1);
         rc = rt_launch_reduce(L.samples, (double *)d_tiles_out, n_owned, L.s_count, pass == 0 && !accumulate,
                               pass == n_pass - 1 && finalize, p->spp, p->width,
                               p->height, p->shard_index, p->shard_count, stream);
         if (rc != 0) return hip_fail((hipError_t)rc, "reduce_kernel launch");
     }
+    HIP_TRY(hipEventRecord(sl.done, st));
+    sl.used = true;
     return RT_OK;
 }
 
@@ -467,10 +477,11 @@ int rt_last_kernel_ms(rt_scene *s, float *ms) {
     if (!s->timed) return fail(RT_ERR_STATE, "no render has been launched on this scene");
     HIP_TRY(hipSetDevice(s->device));
     float total = 0.0f;
-    for (int i = 0; i + 1 < s->events_used; i += 2) {
+    const rt_scene::RenderSlot &sl = s->slots[s->last_slot];
+    for (int i = 0; i + 1 < sl.events_used; i += 2) {
         float t = 0.0f;
-        HIP_TRY(hipEventSynchronize(s->events[(size_t)i + 1]));
-        HIP_TRY(hipEventElapsedTime(&t, s->events[(size_t)i], s->events[(size_t)i + 1]));
+        HIP_TRY(hipEventSynchronize(sl.events[(size_t)i + 1]));
+        HIP_TRY(hipEventElapsedTime(&t, sl.events[(size_t)i], sl.events[(size_t)i + 1]));
         total += t;
     }
     *ms = total;

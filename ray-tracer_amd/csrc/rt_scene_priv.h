@@ -24,26 +24,38 @@ struct rt_scene {
     // cached occupancy query of the last kernel variant used
     unsigned occ_key = 0xFFFFFFFFu, occ_lds = 0;
     int occ_per_cu = 0, occ_n_cu = 0;
-    // per-sample radiance workspace (grown on demand, reused between renders) + job counter
-    void *d_samples = nullptr;
-    size_t samples_bytes = 0;
-    void *d_job_counter = nullptr;
-    // HIP events bracketing each render_kernel launch of the last render
-    std::vector<hipEvent_t> events;
-    int events_used = 0;
+    // A render in flight owns one slot: the per-sample radiance workspace (grown on demand, reused between renders), the
+    // job counter of its launches, the HIP events bracketing each render_kernel launch, and `done`, recorded behind its
+    // last kernel.  Two slots let consecutive renders on different streams overlap (the next render's workgroups fill
+    // the CUs while the previous one's few 100-segment paths finish); a caller that waits for each render only ever
+    // touches slot 0.
+    struct RenderSlot {
+        void *d_samples = nullptr;
+        size_t samples_bytes = 0;
+        void *d_job_counter = nullptr;
+        hipEvent_t done = nullptr;
+        bool used = false;
+        std::vector<hipEvent_t> events;
+        int events_used = 0;
+    };
+    RenderSlot slots[2];
+    int last_slot = 0;
     bool timed = false;
 
     void release_device() {
         if (device >= 0) {
             (void)hipSetDevice(device);
-            for (void **p : {&d_nodes, &d_prim_meta, &d_prim_geo, &d_prim_extra, &d_xforms, &d_materials, &d_textures, &d_blob,
-                             &d_samples, &d_job_counter}) {
+            for (void **p : {&d_nodes, &d_prim_meta, &d_prim_geo, &d_prim_extra, &d_xforms, &d_materials, &d_textures, &d_blob}) {
                 if (*p) (void)hipFree(*p);
                 *p = nullptr;
             }
-            for (hipEvent_t e : events) (void)hipEventDestroy(e);
-            events.clear();
-            samples_bytes = 0;
+            for (RenderSlot &sl : slots) {
+                if (sl.d_samples) (void)hipFree(sl.d_samples);
+                if (sl.d_job_counter) (void)hipFree(sl.d_job_counter);
+                if (sl.done) (void)hipEventDestroy(sl.done);
+                for (hipEvent_t e : sl.events) (void)hipEventDestroy(e);
+                sl = RenderSlot();
+            }
         }
         device_bytes = 0;
     }

@@ -462,3 +462,31 @@ def test_lean_general_kernel_on_a_large_scene(rt, scenes, oracle, gpu_device):
     img = sc.render(cam, 96, 64, 6, 50, seed=9)
     ref = oracle.build_oracle(d).render(96, 64, 6, 50, seed=9, iterative=True, nthreads=8)
     _close(img, ref, max_bad=2)
+
+
+def test_device_renders_in_flight_on_two_streams(rt, scenes, gpu_device):
+    """A scene keeps two render slots (workspace, job counter, events): renders enqueued back to back on alternating
+    streams, never synchronised in between, overlap on the device; a third one is ordered behind the slot it reuses.
+    Every image equals its synchronous render; sizes differ, so the slots' workspaces are also regrown in flight."""
+    import torch
+    d = scenes.book_one(1, 1.5)
+    sc, cam = scenes.build_product(d, device=gpu_device)
+    dev = torch.device("cuda", gpu_device)
+    jobs = [(240, 160, 24, 11), (96, 64, 6, 12), (300, 200, 16, 13), (72, 40, 3, 14), (240, 160, 24, 15), (128, 96, 9, 16)]
+    want = [sc.render(cam, W, H, spp, 50, seed=seed) for (W, H, spp, seed) in jobs]
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    tiles, images = [], []
+    torch.cuda.synchronize()
+    for i, (W, H, spp, seed) in enumerate(jobs):
+        st = streams[i & 1]
+        n = rt.shard_tile_count(W, H, 0, 1)
+        with torch.cuda.stream(st):
+            t = torch.zeros(n * 64 * 3, dtype=torch.float64, device=dev)
+            im = torch.zeros(H * W * 3, dtype=torch.float64, device=dev)
+            sc.render_tiles_device(cam, W, H, spp, 50, seed, (0, 1), t.data_ptr(), None, st.cuda_stream)
+            rt.unpack_tiles_device(t.data_ptr(), n, 1, W, H, im.data_ptr(), st.cuda_stream)
+        tiles.append(t)
+        images.append(im)
+    torch.cuda.synchronize()
+    for (W, H, spp, seed), im, ref in zip(jobs, images, want):
+        assert np.array_equal(im.cpu().numpy().reshape(H, W, 3), ref), (W, H, spp, seed)
