@@ -115,7 +115,8 @@ def main():
     n_buf = 2 if a.pipeline else 1
     mines = [torch.zeros(pad_tiles * 64 * 3, dtype=torch.float64, device=dev) for _ in range(n_buf)]
     gathereds = [torch.zeros(world * pad_tiles * 64 * 3, dtype=torch.float64, device=dev) if rank == 0 else None for _ in range(n_buf)]
-    render_streams = [torch.cuda.Stream(device=dev) for _ in range(n_buf)]
+    # default: the current stream, as ever; only the --pipeline experiment creates side streams
+    render_streams = [torch.cuda.Stream(device=dev) for _ in range(n_buf)] if a.pipeline else [torch.cuda.current_stream()]
     mine = mines[0]
     # rank 0: double-buffered image + a copy stream, so the device->host copy of step k overlaps the render of
     # step k+1 (every copy still completes inside the timed region: sync() waits for all streams)
