@@ -28,6 +28,7 @@ struct Options {
     std::string checkpoint; // raw sums + progress, rewritten after every pass; an existing matching file is resumed
     int passes = 1;
     bool describe = false;
+    bool png_on_stdout = false; // examples/main.rs writes its PNG to stdout (`> image.png`); the other drivers print P3 text
 };
 
 inline Options parse(int argc, char **argv, int w, int h, int spp) {
@@ -218,7 +219,7 @@ inline int run(const Options &o, const std::vector<SpritePtr> &sprites, const Pe
         for (size_t i = 0; i < buffer.size(); ++i) buffer[i] = Vec3(sums[i * 3] / n, sums[i * 3 + 1] / n, sums[i * 3 + 2] / n);
     }
     const std::string path = o.out == "-" ? "/dev/stdout" : o.out;
-    if (path.size() > 4 && path.compare(path.size() - 4, 4, ".png") == 0)
+    if ((o.out == "-" && o.png_on_stdout) || (path.size() > 4 && path.compare(path.size() - 4, 4, ".png") == 0))
         write_png(path, buffer, o.width, o.height); // RGBA8 like examples/main.rs:105-135
     else
         write_ppm(path, buffer, o.width, o.height); // P3 text like println! in the reference

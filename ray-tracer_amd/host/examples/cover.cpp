@@ -72,6 +72,7 @@ static std::vector<SpritePtr> finalScene(uint64_t scene_seed) {
 int main(int argc, char **argv) {
     try {
         Options o = parse(argc, argv, 800, 800, 1000);
+        o.png_on_stdout = true; // examples/main.rs:105-140: `cargo run --release --example main > image.png`
         PerspectiveCamera camera(Vec3(555.0 / 2.0 + 200.0, 550.0 / 2.0, -600.0), Vec3(555.0 / 2.0, 555.0 / 2.0, 0.0), Vec3(0.0, 1.0, 0.0),
                                  to_radians(40.0), (double)o.width / (double)o.height, 10.0, 0.0);
         return run(o, finalScene(o.scene_seed), camera);

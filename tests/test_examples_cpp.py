@@ -165,3 +165,7 @@ def test_cpp_cover_driver_writes_the_reference_png(binaries, rt, scenes, gpu_dev
     got = read_png_rgb(out)
     assert got.shape == (H, W, 3)
     assert np.array_equal(got, rt.tonemap_png8(img)[::-1])
+    # like the reference (`cargo run --example main > image.png`) the cover driver's stdout is that same PNG
+    piped = subprocess.run([str(binaries / "cover"), "--width", str(W), "--height", str(H), "--spp", str(spp), "--depth", "50",
+                            "--seed", "3", "--scene-seed", "2"], check=True, stdout=subprocess.PIPE).stdout
+    assert piped == out.read_bytes()
