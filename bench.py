@@ -177,6 +177,7 @@ def main():
         sc.render_tiles_device(cam, W, H, spp, depth, a.seed, (rank, world), mine.data_ptr(), None, stream)
         per_launch.append(sc.last_kernel_ms())
     kernel_avg_ms = float(np.mean(per_launch))
+    launch_cfg = sc.last_launch_config()
 
     tmax = torch.tensor([dt, kernel_avg_ms], dtype=torch.float64, device=dev)
     if world > 1:
@@ -217,7 +218,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu_pmc": valu,
                          "note": "algorithmic bytes are served from LDS/L1/L2 (scene < 100 KB): the kernel is VALU-issue bound, see DESIGN.md",
-                         "kernel": "render_kernel", "kernel_ms": kernel_avg_ms, "algorithmic_bytes_per_sample": bytes_per_sample,
+                         "kernel": "render_kernel", "kernel_ms": kernel_avg_ms, "launch": launch_cfg, "algorithmic_bytes_per_sample": bytes_per_sample,
                          "segments_per_sample": cnt["segments"] / ns, "nodes_per_sample": cnt["nodes_visited"] / ns,
                          "prims_per_sample": cnt["prims_tested"] / ns,
                          "simd_utilisation": {b: cnt[b + "_lane"] / max(1, 64 * cnt[b + "_wave"]) for b in ("node", "leaf", "shade")},

@@ -187,6 +187,21 @@ int rt_unpack_tiles_device(const void *d_gathered, int tiles_per_shard_padded, i
 /* time (ms) the last rt_render / rt_render_tiles_device kernel took on its stream,
  * measured with HIP events recorded around the launch; blocks until it finished */
 int rt_last_kernel_ms(rt_scene *, float *ms);
+/* how the last render on this scene was launched (diagnostics; the figures rocprofv3 prints for VGPRs / LDS of a
+ * dispatch are not reliable for these kernels): persistent workgroups, threads per workgroup, dynamic LDS per
+ * workgroup, resident workgroups per CU, CUs, passes over the sample workspace, jobs of the last pass and their size,
+ * kernel family feature bits (1 general prims, 2 media, 4 textures), whether the node array is in LDS and the
+ * swap-at-shade queues are in use, and the bytes of per-sample workspace the render used */
+typedef struct rt_launch_config {
+    int blocks, block_threads;
+    unsigned lds_bytes;
+    int blocks_per_cu, n_cu;
+    int passes, n_jobs, job_spp;
+    unsigned kernel_features;
+    int lds_nodes, swap;
+    size_t workspace_bytes;
+} rt_launch_config;
+int rt_last_launch_config(rt_scene *, rt_launch_config *out);
 
 /* ---- output: tone map + P3 text of the drivers (examples/book-one.rs:28-30,90-100):
  *      gamma 2, clamp high, truncate, NaN / negative -> 255 (Q13); rows top-down ---- */

@@ -317,6 +317,8 @@ struct Scene {
     std::unique_ptr<Object> world;
     int world_nodes = 0;
     int medium_slots = 0;
+    double hyp_param = 0.0;
+    unsigned hypothesis = 0; // ORC_HYP_*: earlier forms of the reference's code the cover.png probes try (never a default)
     // camera (camera.rs:10-21)
     Vec3 eye{0, 0, 0}, lowerLeft{0, 0, 0}, horizontal{0, 0, 0}, vertical{0, 0, 0};
     double lensRadius = 0.0;
@@ -359,7 +361,7 @@ inline double schlickReflectionProbability(double theta, double n1, double n2) {
 struct Dielectric : Material { // material.rs:122-193
     double refractive;
     explicit Dielectric(double r) : refractive(r) {}
-    bool scatter(const Scene &, Ctx &c, const Ray &rayIn, const HitRecord &rec, Ray *sc, Vec3 *att) const override {
+    bool scatter(const Scene &s, Ctx &c, const Ray &rayIn, const HitRecord &rec, Ray *sc, Vec3 *att) const override {
         *att = v3(1.0, 1.0, 1.0);
         double ratio;
         Vec3 normal = rec.normal;
@@ -373,7 +375,16 @@ struct Dielectric : Material { // material.rs:122-193
         if (refracted(rayIn.direction, normal, ratio, &refr)) {
             double theta = std::acos(-dot(rayIn.direction, normal));
             double u = c.range01(); // drawn before the probability is evaluated (operand order)
-            if (u < schlickReflectionProbability(theta, ratio, 1.0)) {
+            double pr = schlickReflectionProbability(theta, ratio, 1.0);
+            if (s.hypothesis) { // cover.png probes only
+                const bool inside = ratio > 1.0;
+                if ((s.hypothesis & ORC_HYP_NO_FRESNEL) || ((s.hypothesis & ORC_HYP_NO_INSIDE_FRESNEL) && inside)) pr = 0.0;
+                if ((s.hypothesis & ORC_HYP_SCHLICK_OUTSIDE_ANGLE) && inside) {
+                    Vec3 rn = normalized(refr);
+                    pr = schlickReflectionProbability(std::acos(dot(rn, rec.normal)), ratio, 1.0);
+                }
+            }
+            if (u < pr) {
                 *sc = Ray{rec.intersection, reflected(rayIn.direction, rec.normal)};
             } else {
                 *sc = Ray{rec.intersection, normalized(refr)};
@@ -393,8 +404,10 @@ struct DiffuseLight : Material { // material.rs:274-298
 struct Isotropic : Material { // material.rs:302-326
     int albedo;
     explicit Isotropic(int t) : albedo(t) {}
-    bool scatter(const Scene &s, Ctx &c, const Ray &, const HitRecord &rec, Ray *sc, Vec3 *att) const override {
-        *sc = Ray{rec.intersection, normalized(randomInUnitSphere(c))};
+    bool scatter(const Scene &s, Ctx &c, const Ray &rayIn, const HitRecord &rec, Ray *sc, Vec3 *att) const override {
+        Vec3 p = randomInUnitSphere(c);
+        if (s.hypothesis & ORC_HYP_ISOTROPIC_FORWARD) p = p + rayIn.direction * s.hyp_param; // probe: a forward-biased lobe
+        *sc = Ray{rec.intersection, (s.hypothesis & ORC_HYP_ISOTROPIC_UNNORMALIZED) ? p : normalized(p)}; // probe: the book's listing
         *att = s.textures[albedo]->value(s, rec.u, rec.v, rec.intersection);
         return true;
     }
@@ -551,13 +564,16 @@ struct ConstantMedium : Object { // volume.rs:18-101
             return true;
         }
         // origin inside the boundary
+        if (s.hypothesis & ORC_HYP_INSIDE_NONE) return false; // the book's listing as the reference's comment reads it (volume.rs:44-45)
         double distanceInsideGeometry = record1.t;
         double distance = (-1.0 / density) * std::log(c.keyed01());
         if (distance > distanceInsideGeometry) return false;
         rec->u = record1.u;
         rec->v = record1.v;
-        rec->t = distance;
+        rec->t = distance; // volume.rs:90 "written wrong originally"
         rec->intersection = ray.at(distance);
+        if (s.hypothesis & ORC_HYP_INSIDE_T_ADDS_T1) rec->t = record1.t + distance;
+        if (s.hypothesis & ORC_HYP_INSIDE_POINT_ADDS_T1) rec->intersection = ray.at(record1.t + distance);
         rec->normal = record1.normal;
         rec->material = -1;
         return true;
@@ -860,6 +876,8 @@ extern "C" {
 orc_scene *orc_scene_new(void) { return new orc_scene; }
 void orc_scene_free(orc_scene *p) { delete p; }
 
+void orc_set_hypothesis(orc_scene *p, unsigned flags) { p->s.hypothesis = flags; }
+void orc_set_hypothesis_param(orc_scene *p, double v) { p->s.hyp_param = v; }
 int orc_tex_solid(orc_scene *p, double r, double g, double b) {
     p->s.textures.emplace_back(new SolidColor(v3(r, g, b)));
     return (int)p->s.textures.size() - 1;

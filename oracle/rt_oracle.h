@@ -37,6 +37,19 @@ typedef struct orc_scene orc_scene;
 orc_scene *orc_scene_new(void);
 void orc_scene_free(orc_scene *);
 
+/* cover.png probes only (tools/blue_hypotheses.py): earlier forms of ConstantMedium::hit that the reference's own
+ * comments hint at.  Never set by tests that pin parity; the product has no counterpart. */
+#define ORC_HYP_INSIDE_T_ADDS_T1 1u     /* origin-inside branch: t = record1.t + distance (src/volume.rs:90 "written wrong originally") */
+#define ORC_HYP_INSIDE_POINT_ADDS_T1 2u /* ... and the point taken at that t */
+#define ORC_HYP_INSIDE_NONE 4u          /* origin-inside branch returns None, the book's listing (comment at src/volume.rs:44-45) */
+#define ORC_HYP_ISOTROPIC_UNNORMALIZED 8u   /* Isotropic::scatter keeps randomInUnitSphere() un-normalised (the book's listing) */
+#define ORC_HYP_NO_INSIDE_FRESNEL 16u       /* Dielectric: no Schlick reflection on the way out (only total internal reflection) */
+#define ORC_HYP_NO_FRESNEL 32u              /* Dielectric: no Schlick reflection at all ("forgot the Fresnel effect", src/material.rs:160) */
+#define ORC_HYP_SCHLICK_OUTSIDE_ANGLE 64u   /* Dielectric: Schlick with the angle on the air side when leaving the glass */
+#define ORC_HYP_ISOTROPIC_FORWARD 128u       /* Isotropic::scatter direction = normalize(randomInUnitSphere() + param * d_in) */
+void orc_set_hypothesis(orc_scene *, unsigned flags);
+void orc_set_hypothesis_param(orc_scene *, double value);
+
 /* textures (src/material.rs:196-271) -> texture id */
 int orc_tex_solid(orc_scene *, double r, double g, double b);
 int orc_tex_checker(orc_scene *, int black, int white);

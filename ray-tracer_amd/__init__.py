@@ -67,6 +67,15 @@ class rt_scene_info(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class rt_launch_config(C.Structure):
+    _fields_ = [("blocks", C.c_int), ("block_threads", C.c_int), ("lds_bytes", C.c_uint), ("blocks_per_cu", C.c_int),
+                ("n_cu", C.c_int), ("passes", C.c_int), ("n_jobs", C.c_int), ("job_spp", C.c_int),
+                ("kernel_features", C.c_uint), ("lds_nodes", C.c_int), ("swap", C.c_int), ("workspace_bytes", C.c_size_t)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
 _D = C.c_double
 _DP = C.POINTER(C.c_double)
 _VP = C.c_void_p
@@ -105,6 +114,7 @@ ABI = {
     "rt_render_tiles_device": (C.c_int, [_VP, C.POINTER(rt_camera), C.POINTER(rt_render_params), _VP, _VP, _VP]),
     "rt_unpack_tiles_device": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, _VP]),
     "rt_last_kernel_ms": (C.c_int, [_VP, C.POINTER(C.c_float)]),
+    "rt_last_launch_config": (C.c_int, [_VP, C.POINTER(rt_launch_config)]),
     "rt_tonemap_rgb8": (None, [_DP, C.c_size_t, C.POINTER(C.c_uint8)]),
     "rt_write_ppm_p3": (C.c_int, [C.c_char_p, _DP, C.c_int, C.c_int]),
     "rt_write_png_rgba8": (C.c_int, [C.c_char_p, _DP, C.c_int, C.c_int]),
@@ -302,6 +312,11 @@ class Scene:
         ms = C.c_float()
         _check(lib().rt_last_kernel_ms(self._h, C.byref(ms)))
         return float(ms.value)
+
+    def last_launch_config(self) -> dict:
+        lc = rt_launch_config()
+        _check(lib().rt_last_launch_config(self._h, C.byref(lc)))
+        return lc.as_dict()
 
 
 class Camera:

@@ -367,7 +367,9 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     } else {
         rc = rt_persistent_blocks(feat, lens, count, lds_mode, lds_bytes, &per_cu, &n_cu);
         if (rc != 0) return hip_fail((hipError_t)rc, "occupancy query");
-        if (per_cu < 1) per_cu = 1;
+        if (per_cu < 1) // never clamp silently: a persistent grid sized on a wrong occupancy runs at half speed
+            return fail(RT_ERR_DEVICE, "occupancy query says the render kernel does not fit a CU with " + std::to_string(lds_bytes) +
+                                           " bytes of LDS per workgroup");
         s->occ_key = occ_key;
         s->occ_lds = lds_bytes;
         s->occ_per_cu = per_cu;
@@ -377,6 +379,7 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     L.job_counter = (unsigned int *)sl.d_job_counter;
     L.counters = count ? (RtCounters *)d_counters : nullptr;
     const int n_pass = (n_spp + chunk - 1) / chunk;
+    int last_blocks = 0;
     while ((int)sl.events.size() < 2 * n_pass) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
@@ -400,6 +403,7 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
         const long long waves_per_block = block / 64;
         const long long want = (n_jobs + waves_per_block - 1) / waves_per_block;
         const int blocks = (int)std::min<long long>((long long)per_cu * n_cu, want > 0 ? want : 1);
+        last_blocks = blocks;
         HIP_TRY(hipMemsetAsync(sl.d_job_counter, 0, sizeof(unsigned int), st));
         HIP_TRY(hipEventRecord(sl.events[(size_t)(2 * pass)], st));
         rc = rt_launch_render(&L, feat, lens, count, lds_mode, blocks, lds_bytes, stream);
@@ -413,6 +417,19 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     }
     HIP_TRY(hipEventRecord(sl.done, st));
     sl.used = true;
+    rt_launch_config &lc = s->last_launch;
+    lc.blocks = last_blocks;
+    lc.block_threads = (int)block;
+    lc.lds_bytes = lds_bytes;
+    lc.blocks_per_cu = per_cu;
+    lc.n_cu = n_cu;
+    lc.passes = n_pass;
+    lc.n_jobs = L.n_jobs;
+    lc.job_spp = L.job_spp;
+    lc.kernel_features = feat;
+    lc.lds_nodes = ldsnodes;
+    lc.swap = swap;
+    lc.workspace_bytes = need;
     return RT_OK;
 }
 
@@ -485,6 +502,14 @@ int rt_last_kernel_ms(rt_scene *s, float *ms) {
         total += t;
     }
     *ms = total;
+    return RT_OK;
+}
+
+int rt_last_launch_config(rt_scene *s, rt_launch_config *out) {
+    if (!s || !out) return fail(RT_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (!s->timed) return fail(RT_ERR_STATE, "no render has been launched on this scene");
+    *out = s->last_launch;
     return RT_OK;
 }
 

@@ -5,6 +5,7 @@
 #define RT_SCENE_PRIV_H
 
 #include "rt_host.h"
+#include "../../include/rt_mi355x.h"
 
 #include <hip/hip_runtime_api.h>
 
@@ -41,6 +42,7 @@ struct rt_scene {
     RenderSlot slots[2];
     int last_slot = 0;
     bool timed = false;
+    rt_launch_config last_launch{}; // of the last render_range call
 
     void release_device() {
         if (device >= 0) {

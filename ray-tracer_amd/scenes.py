@@ -205,8 +205,11 @@ def earth_texture(w: int = 1024, h: int = 512) -> np.ndarray:
     return img
 
 
-def cover(scene_seed: int = 1, aspect: float = 1.0, with_fog: bool = True) -> SceneDesc:
-    """finalScene() of examples/main.rs:156-330 + camera :49-61."""
+def cover(scene_seed: int = 1, aspect: float = 1.0, with_fog: bool = True, heights=None) -> SceneDesc:
+    """finalScene() of examples/main.rs:156-330 + camera :49-61.
+    heights: optional 20x20 array overriding the random floor-box heights y1[i][j] (NaN = keep the random one); the
+    generator is advanced all the same, so everything else of the scene stays as `scene_seed` makes it
+    (used by the cover.png probes, tools/blue_probe.py, tools/fit_cover_floor.py)."""
     d = SceneDesc(name="book-two-cover")
     g = HostRng(scene_seed)
     ground = d.lambertian_rgb((0.48, 0.83, 0.53))
@@ -219,6 +222,8 @@ def cover(scene_seed: int = 1, aspect: float = 1.0, with_fog: bool = True) -> Sc
             z0 = -1000.0 + float(j) * w
             x1 = x0 + w
             y1 = g.gen_range(1.0, 101.0)
+            if heights is not None and heights[i][j] == heights[i][j]:
+                y1 = float(heights[i][j])
             z1 = z0 + w
             cubes.append(d.sprite(d.geom("cube", x1 - x0, y1 - y0, z1 - z0), ground,
                                   mat4_translation(((x0 + x1) / 2.0, (y0 + y1) / 2.0, (z0 + z1) / 2.0))))
