@@ -86,11 +86,22 @@ int rt_add_material_isotropic(rt_scene *, int albedo_texture);
 /* ---- geometries: Sphere::new (src/geometry.rs:17-19), Rectangle::new (:139-144),
  *      BoundingVolumeHierarchyNode::new(Cube::new(w,h,d)) (src/geometry.rs:254-286 as
  *      wrapped by examples/cornell-box.rs:85-101), ConstantMedium::new(boundary, density)
- *      (src/volume.rs:25-30; boundary must be a sphere geometry) ---- */
+ *      (src/volume.rs:25-30; boundary = any geometry but another medium: ConstantMedium<T: Hit>) ---- */
 int rt_add_geometry_sphere(rt_scene *, double radius);
 int rt_add_geometry_rectangle(rt_scene *, double width, double height);
 int rt_add_geometry_cube(rt_scene *, double width, double height, double depth);
 int rt_add_geometry_constant_medium(rt_scene *, int boundary_geometry, double density);
+/* TransformedGeometry::new(geometry, M) (src/geometry.rs:185-246): a geometry under one more matrix, without a material */
+int rt_add_geometry_transformed(rt_scene *, int geometry, const double transform[16]);
+/* BoundingVolumeHierarchyNode::new(vec![sprites...]) used as a GEOMETRY -- the reference's instancing
+ * (src/sprite.rs:87-93 with T = BoundingVolumeHierarchyNode, src/optimize.rs:339-343: children are Arc<dyn Bound>).
+ * The listed sprites are moved into the node (like the Vec the constructor takes): they stop being part of the world's
+ * own list and are hit only through sprites whose geometry is this node.  A child without a material is the reference's
+ * TransformedGeometry.  Whatever material a child carries, Sprite::hit of the enclosing sprite replaces it
+ * (src/sprite.rs:119-127).  RT_ERR_EMPTY for an empty list (None upstream).  Nesting: up to 4 transform levels above
+ * a sphere / rectangle.  At commit every instance is expanded into leaves that keep the matrices of all their levels --
+ * the traversal stays one flat BVH and the arithmetic per level is the reference's. */
+int rt_add_geometry_bvh(rt_scene *, const int *sprites, int n_sprites);
 
 /* ---- Sprite::builder().geometry(g).material(m).transform(M).build()
  *      (src/sprite.rs:22-72).  geometry / material = -1 is the reference's None:
@@ -242,6 +253,7 @@ int rt_probe_device_math(int device, const double *a, const double *b, int n, do
 #define RT_FEAT_MEDIUM 4u     /* ConstantMedium */
 #define RT_FEAT_TEXTURED 8u   /* checker / image textures (uv needed) */
 #define RT_FEAT_LENS 16u
+#define RT_FEAT_MEDIUM_GENERAL 32u /* a ConstantMedium whose boundary is not a plain sphere under a pure translation */
 
 #ifdef __cplusplus
 }

@@ -107,6 +107,15 @@ RT_HD uint64_t rt_rng_keyed_from_base(uint64_t base, uint32_t segment, uint32_t 
     return rt_mix64(base + n * RT_RNG_GAMMA);
 }
 
+/* Key of the free-flight draws of a ConstantMedium that sits inside instanced geometry (a Sprite whose geometry is a
+ * BoundingVolumeHierarchyNode of further sprites): every instance needs draws of its own.  path_hash folds the
+ * creation indices of the sprites from the world's list down to the medium's sprite,
+ *     h = index(top) + 1;  h = h * RT_RNG_PATH_MUL + index(child) + 1  for every level below,
+ * and the key is the low 10 bits of its mix.  A medium sprite of the world's own list keeps its creation-order slot
+ * (round-1 results unchanged).  Two media whose keys collide share their draws on a segment (1 pair in 1024). */
+#define RT_RNG_PATH_MUL 1000003ull
+RT_HD uint32_t rt_medium_key_nested(uint64_t path_hash) { return (uint32_t)(rt_mix64(path_hash) & 0x3FFull); }
+
 RT_HD double rt_bits_to_double(uint64_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __longlong_as_double((long long)b);

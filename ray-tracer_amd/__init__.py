@@ -105,6 +105,8 @@ ABI = {
     "rt_add_geometry_rectangle": (C.c_int, [_VP, _D, _D]),
     "rt_add_geometry_cube": (C.c_int, [_VP, _D, _D, _D]),
     "rt_add_geometry_constant_medium": (C.c_int, [_VP, C.c_int, _D]),
+    "rt_add_geometry_transformed": (C.c_int, [_VP, C.c_int, _DP]),
+    "rt_add_geometry_bvh": (C.c_int, [_VP, C.POINTER(C.c_int), C.c_int]),
     "rt_add_sprite": (C.c_int, [_VP, C.c_int, C.c_int, _DP]),
     "rt_scene_commit": (C.c_int, [_VP, C.c_int]),
     "rt_camera_perspective": (C.c_int, [C.POINTER(rt_camera), _DP, _DP, _DP, _D, _D, _D, _D]),
@@ -260,6 +262,16 @@ class Scene:
 
     def constant_medium(self, boundary, density):
         return _check(lib().rt_add_geometry_constant_medium(self._h, boundary, float(density)))
+
+    def transformed(self, geometry, transform):
+        """TransformedGeometry::new(geometry, M) (src/geometry.rs:185-246)"""
+        m = None if transform is None else _dp(np.ascontiguousarray(transform, dtype=np.float64).reshape(16))
+        return _check(lib().rt_add_geometry_transformed(self._h, geometry, m))
+
+    def bvh(self, sprites):
+        """BoundingVolumeHierarchyNode::new(sprites) as a geometry: the sprites are moved into the node (instancing)"""
+        arr = (C.c_int * len(sprites))(*[int(v) for v in sprites])
+        return _check(lib().rt_add_geometry_bvh(self._h, arr, len(sprites)))
 
     def sprite(self, geometry, material, transform=None):
         m = None if transform is None else _dp(np.ascontiguousarray(transform, dtype=np.float64).reshape(16))

@@ -157,9 +157,36 @@ int rt_add_geometry_cube(rt_scene *s, double w, double h, double d) { return add
 int rt_add_geometry_constant_medium(rt_scene *s, int boundary, double density) {
     if (int e = check_open(s)) return e;
     if (boundary < 0 || (size_t)boundary >= s->ir.geometries.size()) return fail(RT_ERR_INVALID, "medium: unknown boundary geometry");
-    if (s->ir.geometries[(size_t)boundary].kind != rt::GEO_SPHERE)
-        return fail(RT_ERR_UNSUPPORTED, "medium: only a sphere boundary is supported (the reference's examples use nothing else)");
+    if (s->ir.geometries[(size_t)boundary].kind == rt::GEO_MEDIUM)
+        return fail(RT_ERR_UNSUPPORTED, "medium: the boundary of a ConstantMedium cannot itself be a ConstantMedium");
     return add_geometry(s, rt::GEO_MEDIUM, density, 0, 0, boundary);
+}
+int rt_add_geometry_transformed(rt_scene *s, int geometry, const double M[16]) {
+    if (int e = check_open(s)) return e;
+    if (geometry < 0 || (size_t)geometry >= s->ir.geometries.size()) return fail(RT_ERR_INVALID, "transformed: unknown geometry id");
+    const int id = add_geometry(s, rt::GEO_TRANSFORMED, 0, 0, 0, geometry);
+    if (id < 0) return id;
+    if (M)
+        std::memcpy(s->ir.geometries[(size_t)id].M, M, sizeof(double) * 16);
+    else
+        rt::mat4_identity(s->ir.geometries[(size_t)id].M);
+    return id;
+}
+int rt_add_geometry_bvh(rt_scene *s, const int *sprites, int n) {
+    if (int e = check_open(s)) return e;
+    if (n < 0 || (n > 0 && !sprites)) return fail(RT_ERR_INVALID, "bvh: bad sprite list");
+    if (n == 0) return fail(RT_ERR_EMPTY, "BoundingVolumeHierarchyNode::new(vec![]) is None (src/optimize.rs:367-370)");
+    for (int i = 0; i < n; ++i) {
+        if (sprites[i] < 0 || (size_t)sprites[i] >= s->ir.sprites.size()) return fail(RT_ERR_INVALID, "bvh: unknown sprite id");
+        if (s->ir.sprites[(size_t)sprites[i]].owned) return fail(RT_ERR_STATE, "bvh: sprite already moved into another node");
+        for (int j = 0; j < i; ++j)
+            if (sprites[j] == sprites[i]) return fail(RT_ERR_INVALID, "bvh: sprite listed twice");
+    }
+    const int id = add_geometry(s, rt::GEO_BVH, 0, 0, 0, -1);
+    if (id < 0) return id;
+    s->ir.geometries[(size_t)id].children.assign(sprites, sprites + n);
+    for (int i = 0; i < n; ++i) s->ir.sprites[(size_t)sprites[i]].owned = true;
+    return id;
 }
 
 int rt_add_sprite(rt_scene *s, int geometry, int material, const double M[16]) {
@@ -281,6 +308,7 @@ static unsigned kernel_features(const rt_scene *s) {
     if (s->flat.feature_mask & RT_FEAT_GENERAL) f |= 1u;
     if (s->flat.feature_mask & RT_FEAT_MEDIUM) f |= 2u;
     if (s->flat.feature_mask & RT_FEAT_TEXTURED) f |= 4u;
+    if (s->flat.feature_mask & RT_FEAT_MEDIUM_GENERAL) f |= 8u;
     return f;
 }
 

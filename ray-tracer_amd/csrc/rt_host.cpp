@@ -15,6 +15,7 @@
 #include "rt_host.h"
 
 #include "../../include/rt_mi355x.h"
+#include "../../include/rt_rng.h"
 
 #include <algorithm>
 #include <cmath>
@@ -255,26 +256,6 @@ void xform_point(const double M[16], const double p[3], double out[3]) {
     for (int r = 0; r < 3; ++r) out[r] = M[r] * p[0] + M[4 + r] * p[1] + M[8 + r] * p[2] + M[12 + r] * 1.0;
 }
 
-// AABB of the eight transformed corners (src/optimize.rs:149-177 = :205-233)
-Aabb transformed_bound(const Aabb &b, const double M[16]) {
-    const double x0 = b.lo[0], y0 = b.lo[1], z0 = b.lo[2], x1 = b.hi[0], y1 = b.hi[1], z1 = b.hi[2];
-    const double c[8][3] = {{x0, y0, z0}, {x1, y0, z0}, {x0, y1, z0}, {x0, y0, z1},
-                            {x1, y1, z0}, {x1, y0, z1}, {x0, y1, z1}, {x1, y1, z1}};
-    Aabb o;
-    for (int i = 0; i < 3; ++i) {
-        o.lo[i] = kInf;
-        o.hi[i] = -kInf;
-    }
-    for (const auto &p : c) {
-        double q[3];
-        xform_point(M, p, q);
-        for (int i = 0; i < 3; ++i) {
-            if (q[i] < o.lo[i]) o.lo[i] = q[i];
-            if (q[i] > o.hi[i]) o.hi[i] = q[i];
-        }
-    }
-    return o;
-}
 Aabb merged(const Aabb &a, const Aabb &b) { // src/optimize.rs:44-57
     Aabb o;
     for (int i = 0; i < 3; ++i) {
@@ -357,6 +338,246 @@ void cull_box(const Aabb &b, float lo[3], float hi[3]) {
     }
 }
 
+namespace {
+
+// one transform level above a leaf
+struct Link {
+    double M[16], Minv[16];
+    bool translation; // M and M^-1 are pure translations by t and -t: only the offsets enter the arithmetic
+};
+bool make_link(const double M[16], Link *l) {
+    std::memcpy(l->M, M, sizeof l->M);
+    if (!mat4_inversed(M, l->Minv)) return false; // det == 0: unhittable (src/sprite.rs:131-134, src/geometry.rs:241-244)
+    l->translation = is_pure_translation(M) && is_pure_translation(l->Minv) && l->Minv[12] == -M[12] && l->Minv[13] == -M[13] &&
+                     l->Minv[14] == -M[14];
+    return true;
+}
+
+// a sphere or rectangle under its chain, before it becomes a BVH leaf or a medium's boundary prim
+struct Shape {
+    uint32_t kind; // RT_PRIM_SPHERE_C / RT_PRIM_RECT_C
+    double a, b;   // r | w, h
+    std::vector<Link> chain; // outermost first
+};
+struct Leaf {
+    RtPrimMeta meta{};
+    RtPrimGeo geo{};
+    RtPrimExtra extra{};
+    Aabb bound{};
+    std::vector<Link> chain;
+    std::vector<Shape> boundary; // RT_PRIM_MEDIUM_C
+};
+
+// the shape's bound carried through every level of `outer` + `inner` (outermost first): the AABB of the 8 transformed
+// corners.  Tighter than nesting the reference's per-level boxes (src/optimize.rs:128-241) and still a superset of every
+// point the chain arithmetic can map a local hit to (affine images of a box are spanned by its corners).
+Aabb chain_bound(const Aabb &local, const std::vector<Link> &outer, const std::vector<Link> &inner) {
+    const double x0 = local.lo[0], y0 = local.lo[1], z0 = local.lo[2], x1 = local.hi[0], y1 = local.hi[1], z1 = local.hi[2];
+    double c[8][3] = {{x0, y0, z0}, {x1, y0, z0}, {x0, y1, z0}, {x0, y0, z1}, {x1, y1, z0}, {x1, y0, z1}, {x0, y1, z1}, {x1, y1, z1}};
+    Aabb o;
+    for (int i = 0; i < 3; ++i) {
+        o.lo[i] = kInf;
+        o.hi[i] = -kInf;
+    }
+    for (auto &p : c) {
+        double q[3] = {p[0], p[1], p[2]}, r[3];
+        for (size_t k = inner.size(); k-- > 0;) {
+            xform_point(inner[k].M, q, r);
+            std::memcpy(q, r, sizeof q);
+        }
+        for (size_t k = outer.size(); k-- > 0;) {
+            xform_point(outer[k].M, q, r);
+            std::memcpy(q, r, sizeof q);
+        }
+        for (int i = 0; i < 3; ++i) {
+            if (q[i] < o.lo[i]) o.lo[i] = q[i];
+            if (q[i] > o.hi[i]) o.hi[i] = q[i];
+        }
+    }
+    return o;
+}
+Aabb shape_local_bound(const Shape &s) { return s.kind == RT_PRIM_SPHERE_C ? sphere_bound(s.a) : rect_bound(s.a, s.b); }
+
+struct Flattener {
+    const SceneIR &ir;
+    FlatScene &fs;
+    std::vector<Leaf> leaves;
+    uint32_t medium_slots = 0;
+    std::string error;
+    int rc = RT_OK;
+
+    bool fail(int code, const std::string &msg) {
+        if (rc == RT_OK) {
+            rc = code;
+            error = msg;
+        }
+        return false;
+    }
+
+    // every sphere / rectangle below geometry `gi`, each with the transforms between it and `chain`'s end appended
+    bool collect_shapes(int gi, std::vector<Link> chain, std::vector<Shape> *out, int depth) {
+        if (depth > 16) return fail(RT_ERR_UNSUPPORTED, "geometry nesting deeper than 16 levels");
+        const GeometryIR &g = ir.geometries[(size_t)gi];
+        switch (g.kind) {
+        case GEO_SPHERE:
+            out->push_back(Shape{RT_PRIM_SPHERE_C, g.p[0], 0.0, chain});
+            return true;
+        case GEO_RECTANGLE:
+            out->push_back(Shape{RT_PRIM_RECT_C, g.p[0], g.p[1], chain});
+            return true;
+        case GEO_CUBE: { // BoundingVolumeHierarchyNode::new(Cube::new(w, h, d)): six TransformedGeometry<Rectangle>
+            CubeFace f[6];
+            cube_faces(g.p[0], g.p[1], g.p[2], f);
+            for (const CubeFace &face : f) {
+                Link l;
+                if (!make_link(face.M, &l)) continue;
+                std::vector<Link> c = chain;
+                c.push_back(l);
+                out->push_back(Shape{RT_PRIM_RECT_C, face.w, face.h, c});
+            }
+            return true;
+        }
+        case GEO_TRANSFORMED: {
+            Link l;
+            if (!make_link(g.M, &l)) return true; // never hit
+            chain.push_back(l);
+            return collect_shapes(g.boundary, chain, out, depth + 1);
+        }
+        case GEO_BVH:
+            for (int si : g.children) {
+                const SpriteIR &sp = ir.sprites[(size_t)si];
+                if (sp.geometry < 0) continue;
+                Link l;
+                if (!make_link(sp.M, &l)) continue;
+                std::vector<Link> c = chain;
+                c.push_back(l);
+                if (!collect_shapes(sp.geometry, c, out, depth + 1)) return false;
+            }
+            return true;
+        case GEO_MEDIUM:
+            return fail(RT_ERR_UNSUPPORTED, "a ConstantMedium inside the boundary of another ConstantMedium is not supported");
+        }
+        return true;
+    }
+
+    void finish_meta(RtPrimMeta *m, const std::vector<Link> &chain) {
+        uint32_t tmask = 0;
+        for (size_t i = 0; i < chain.size(); ++i)
+            if (chain[i].translation) tmask |= 1u << i;
+        m->kind = (m->kind & 0xFFu) | ((uint32_t)chain.size() << RT_META_CHAIN_SHIFT) | (tmask << RT_META_TMASK_SHIFT);
+    }
+
+    // Emit the leaves below geometry `gi` reached through `chain`; `material` is the outermost sprite's (Sprite::hit
+    // replaces whatever material the inner record carried, src/sprite.rs:119-127); path_hash / path_len identify the
+    // sprites on the way down (keys of the media's random draws, include/rt_rng.h)
+    bool emit(int gi, const std::vector<Link> &chain, uint32_t material, uint64_t path_hash, int path_len, uint32_t top_slot, int depth) {
+        if (depth > 16) return fail(RT_ERR_UNSUPPORTED, "geometry nesting deeper than 16 levels");
+        const GeometryIR &g = ir.geometries[(size_t)gi];
+        switch (g.kind) {
+        case GEO_SPHERE:
+        case GEO_RECTANGLE:
+        case GEO_CUBE: {
+            std::vector<Shape> shapes;
+            if (!collect_shapes(gi, chain, &shapes, depth)) return false;
+            for (const Shape &sh : shapes) {
+                if (sh.chain.size() > RT_MAX_CHAIN)
+                    return fail(RT_ERR_UNSUPPORTED, "more than RT_MAX_CHAIN (4) transform levels above one primitive");
+                Leaf lf;
+                lf.meta.material = material;
+                lf.chain = sh.chain;
+                if (sh.kind == RT_PRIM_SPHERE_C && sh.chain.size() == 1 && sh.chain[0].translation) {
+                    // all of book-one: world-space centre + radius, the arithmetic the 4x4 path performs for a translation
+                    lf.meta.kind = RT_PRIM_SPHERE_T;
+                    lf.geo.g[0] = sh.chain[0].M[12];
+                    lf.geo.g[1] = sh.chain[0].M[13];
+                    lf.geo.g[2] = sh.chain[0].M[14];
+                    lf.geo.g[3] = sh.a;
+                    fs.feature_mask |= RT_FEAT_SPHERE_T;
+                } else {
+                    lf.meta.kind = sh.kind;
+                    lf.geo.g[0] = sh.a;
+                    lf.geo.g[1] = sh.b;
+                    fs.feature_mask |= RT_FEAT_GENERAL;
+                }
+                lf.bound = chain_bound(shape_local_bound(sh), sh.chain, {});
+                pad(&lf.bound);
+                leaves.push_back(std::move(lf));
+            }
+            return true;
+        }
+        case GEO_TRANSFORMED: {
+            Link l;
+            if (!make_link(g.M, &l)) return true;
+            std::vector<Link> c = chain;
+            c.push_back(l);
+            return emit(g.boundary, c, material, path_hash, path_len, top_slot, depth + 1);
+        }
+        case GEO_BVH:
+            for (int si : g.children) {
+                const SpriteIR &sp = ir.sprites[(size_t)si];
+                if (sp.geometry < 0) continue; // geometry None: never hit (src/sprite.rs:95,136)
+                Link l;
+                if (!make_link(sp.M, &l)) continue;
+                std::vector<Link> c = chain;
+                c.push_back(l);
+                if (!emit(sp.geometry, c, material, path_hash * RT_RNG_PATH_MUL + (uint64_t)si + 1ull, path_len + 1, top_slot, depth + 1))
+                    return false;
+            }
+            return true;
+        case GEO_MEDIUM: {
+            if (chain.size() > RT_MAX_CHAIN)
+                return fail(RT_ERR_UNSUPPORTED, "more than RT_MAX_CHAIN (4) transform levels above one primitive");
+            Leaf lf;
+            lf.meta.material = material;
+            lf.chain = chain;
+            // a medium sprite of the world's own list keeps its creation-order slot; a nested one is keyed by its path
+            lf.meta.aux = path_len == 1 ? top_slot : rt_medium_key_nested(path_hash);
+            const GeometryIR &b = ir.geometries[(size_t)g.boundary];
+            fs.feature_mask |= RT_FEAT_MEDIUM;
+            if (b.kind == GEO_SPHERE && chain.size() == 1 && chain[0].translation) {
+                lf.meta.kind = RT_PRIM_MEDIUM_T; // examples/main.rs:241-263
+                lf.geo.g[0] = chain[0].M[12];
+                lf.geo.g[1] = chain[0].M[13];
+                lf.geo.g[2] = chain[0].M[14];
+                lf.geo.g[3] = b.p[0];
+                lf.extra.e[0] = g.p[0];
+                lf.bound = chain_bound(sphere_bound(b.p[0]), chain, {});
+            } else {
+                lf.meta.kind = RT_PRIM_MEDIUM_C;
+                lf.geo.g[0] = g.p[0];
+                if (!collect_shapes(g.boundary, {}, &lf.boundary, depth + 1)) return false;
+                bool first = true;
+                for (const Shape &sh : lf.boundary) {
+                    if (sh.chain.size() > RT_MAX_CHAIN)
+                        return fail(RT_ERR_UNSUPPORTED, "more than RT_MAX_CHAIN (4) transform levels inside a medium's boundary");
+                    const Aabb sb = chain_bound(shape_local_bound(sh), chain, sh.chain);
+                    lf.bound = first ? sb : merged(lf.bound, sb);
+                    first = false;
+                }
+                if (first) return true; // empty boundary: never hit
+                fs.feature_mask |= RT_FEAT_GENERAL | RT_FEAT_MEDIUM_GENERAL;
+            }
+            pad(&lf.bound);
+            leaves.push_back(std::move(lf));
+            return true;
+        }
+        }
+        return true;
+    }
+};
+
+uint32_t push_chain(FlatScene &fs, const std::vector<Link> &chain) {
+    const uint32_t first = (uint32_t)fs.xforms.size();
+    for (const Link &l : chain) {
+        RtXform x;
+        make_xform(l.M, l.Minv, &x);
+        fs.xforms.push_back(x);
+    }
+    return first;
+}
+
+} // namespace
+
 int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
     FlatScene fs;
 
@@ -397,125 +618,63 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
         fs.materials.push_back(d);
     }
 
-    // sprites -> leaf prims (in creation order first; hoisted ones are moved to the front below)
-    struct Leaf {
-        RtPrimMeta meta;
-        RtPrimGeo geo;
-        RtPrimExtra extra;
-        Aabb bound;
-        bool is_group;
-        CubeFace faces[6];
-    };
-    std::vector<Leaf> leaves;
-    uint32_t medium_slots = 0;
-    for (const SpriteIR &s : ir.sprites) {
+    // the world's own sprites -> leaves, in creation order (hoisted ones are moved to the front below); a sprite whose
+    // geometry is a node of further sprites is expanded, every leaf keeping the transforms of all levels above it
+    Flattener fl{ir, fs};
+    for (size_t si = 0; si < ir.sprites.size(); ++si) {
+        const SpriteIR &s = ir.sprites[si];
+        if (s.owned) continue;        // moved into a BoundingVolumeHierarchyNode geometry
         if (s.geometry < 0) continue; // geometry None: never hit (src/sprite.rs:95,136)
         const GeometryIR &g = ir.geometries[(size_t)s.geometry];
         uint32_t slot = 0;
-        if (g.kind == GEO_MEDIUM) slot = (medium_slots++) & 0x3FFu; // slots count sprites in creation order
-        double Minv[16];
-        if (!mat4_inversed(s.M, Minv)) continue; // det == 0: unhittable (src/sprite.rs:131-134)
-        Leaf lf{};
-        RtPrimMeta &p = lf.meta;
-        double *geo = lf.geo.g;
-        p.material = s.material < 0 ? RT_NO_MATERIAL : (uint32_t)s.material;
-        const bool trans = is_pure_translation(s.M);
-        Aabb local{};
-        switch (g.kind) {
-        case GEO_SPHERE:
-            local = sphere_bound(g.p[0]);
-            if (trans) {
-                p.kind = RT_PRIM_SPHERE_T;
-                geo[0] = s.M[12];
-                geo[1] = s.M[13];
-                geo[2] = s.M[14];
-                geo[3] = g.p[0];
-                fs.feature_mask |= RT_FEAT_SPHERE_T;
-            } else {
-                p.kind = RT_PRIM_SPHERE_M;
-                geo[0] = g.p[0];
-                fs.feature_mask |= RT_FEAT_GENERAL;
-            }
-            break;
-        case GEO_RECTANGLE:
-            local = rect_bound(g.p[0], g.p[1]);
-            p.kind = RT_PRIM_RECT_M;
-            geo[0] = g.p[0];
-            geo[1] = g.p[1];
-            fs.feature_mask |= RT_FEAT_GENERAL;
-            break;
-        case GEO_CUBE: {
-            lf.is_group = true;
-            cube_faces(g.p[0], g.p[1], g.p[2], lf.faces);
-            bool first = true;
-            for (const CubeFace &f : lf.faces) {
-                Aabb fb = transformed_bound(rect_bound(f.w, f.h), f.M);
-                local = first ? fb : merged(local, fb);
-                first = false;
-            }
-            p.kind = RT_PRIM_GROUP_M;
-            geo[0] = 6.0;
-            fs.feature_mask |= RT_FEAT_GENERAL;
-            break;
+        if (g.kind == GEO_MEDIUM) slot = (fl.medium_slots++) & 0x3FFu; // slots count the world's medium sprites in creation order
+        Link l;
+        if (!make_link(s.M, &l)) continue; // det == 0: unhittable (src/sprite.rs:131-134)
+        const uint32_t material = s.material < 0 ? RT_NO_MATERIAL : (uint32_t)s.material;
+        if (!fl.emit(s.geometry, {l}, material, (uint64_t)si + 1ull, 1, slot, 0)) {
+            if (err) *err = fl.error;
+            return fl.rc;
         }
-        case GEO_MEDIUM: {
-            const GeometryIR &b = ir.geometries[(size_t)g.boundary];
-            local = sphere_bound(b.p[0]);
-            p.aux = slot;
-            if (trans) {
-                p.kind = RT_PRIM_MEDIUM_T;
-                geo[0] = s.M[12];
-                geo[1] = s.M[13];
-                geo[2] = s.M[14];
-                geo[3] = b.p[0];
-                lf.extra.e[0] = g.p[0];
-            } else {
-                p.kind = RT_PRIM_MEDIUM_M;
-                geo[0] = b.p[0];
-                geo[1] = g.p[0];
-            }
-            fs.feature_mask |= RT_FEAT_MEDIUM;
-            break;
-        }
-        }
-        if (p.kind != RT_PRIM_SPHERE_T && p.kind != RT_PRIM_MEDIUM_T) {
-            RtXform x;
-            make_xform(s.M, Minv, &x);
-            p.xform = (uint32_t)fs.xforms.size();
-            fs.xforms.push_back(x);
-        }
-        lf.bound = transformed_bound(local, s.M);
-        pad(&lf.bound);
-        leaves.push_back(lf);
     }
+    std::vector<Leaf> &leaves = fl.leaves;
     if (leaves.empty()) {
         if (err) *err = "empty scene: BoundingVolumeHierarchyNode::new(vec![]) is None (src/optimize.rs:367-370)";
         return RT_ERR_EMPTY;
     }
     if (leaves.size() > RT_REF_MAX) {
-        if (err) *err = "more than 32767 sprites: outside the 16-bit node references of this build";
+        if (err) *err = "more than 32767 primitives: outside the 16-bit node references of this build";
         return RT_ERR_UNSUPPORTED;
     }
 
-    // hoist scene-spanning prims (book-one's sky and ground spheres, main.rs's fog): their
-    // boxes make every ancestor an always-hit, so they are tested up front for each
-    // segment and give the traversal an early upper bound instead.
-    auto area = [](const Aabb &b) {
-        const double dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
-        return 2.0 * (dx * dy + dy * dz + dz * dx);
-    };
-    Aabb root = leaves[0].bound;
-    for (const Leaf &l : leaves) root = merged(root, l.bound);
+    // hoist scene-FILLING prims (book-one's sky and ground spheres, main.rs's fog): their boxes make every ancestor
+    // an always-hit, so they are tested up front for each segment and give the traversal an early upper bound instead.
+    // The measure is the box VOLUME: a wall of the Cornell box spans the scene too, but its box is flat and culls well.
+    auto volume = [](const Aabb &b) { return (b.hi[0] - b.lo[0]) * (b.hi[1] - b.lo[1]) * (b.hi[2] - b.lo[2]); };
     std::vector<size_t> order(leaves.size());
     std::iota(order.begin(), order.end(), (size_t)0);
     std::vector<size_t> hoist;
     {
-        std::vector<size_t> by_area = order;
-        std::stable_sort(by_area.begin(), by_area.end(), [&](size_t a, size_t b) { return area(leaves[a].bound) > area(leaves[b].bound); });
-        for (size_t i : by_area) {
-            if ((int)hoist.size() >= RT_MAX_HOISTED) break;
-            if (!(area(leaves[i].bound) >= 0.1 * area(root))) break;
-            hoist.push_back(i);
+        // peel off the largest box while it still fills >= 10 % of the box of what is left (sky first, then the ground
+        // under it, ...): judged against the REMAINING prims, so a big ground inside a much bigger sky still qualifies
+        std::vector<char> gone(leaves.size(), 0);
+        while ((int)hoist.size() < RT_MAX_HOISTED && hoist.size() + 1 < leaves.size()) {
+            bool first = true;
+            Aabb root{};
+            size_t big = 0;
+            double big_v = -1.0;
+            for (size_t i = 0; i < leaves.size(); ++i) {
+                if (gone[i]) continue;
+                root = first ? leaves[i].bound : merged(root, leaves[i].bound);
+                first = false;
+                const double v = volume(leaves[i].bound);
+                if (v > big_v) {
+                    big_v = v;
+                    big = i;
+                }
+            }
+            if (!(volume(root) > 0.0) || !(big_v >= 0.1 * volume(root))) break;
+            gone[big] = 1;
+            hoist.push_back(big);
         }
         std::sort(hoist.begin(), hoist.end());
     }
@@ -524,39 +683,38 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
         if (!std::binary_search(hoist.begin(), hoist.end(), i)) final_order.push_back(i);
     fs.n_hoisted = (int)hoist.size();
     for (size_t i : final_order) {
-        fs.prim_meta.push_back(leaves[i].meta);
-        fs.prim_geo.push_back(leaves[i].geo);
-        fs.prim_extra.push_back(leaves[i].extra);
-        fs.prim_bounds.push_back(leaves[i].bound);
+        Leaf &lf = leaves[i];
+        if (lf.meta.kind != RT_PRIM_SPHERE_T && lf.meta.kind != RT_PRIM_MEDIUM_T) {
+            lf.meta.xform = push_chain(fs, lf.chain);
+            fl.finish_meta(&lf.meta, lf.chain);
+        }
+        fs.prim_meta.push_back(lf.meta);
+        fs.prim_geo.push_back(lf.geo);
+        fs.prim_extra.push_back(lf.extra);
+        fs.prim_bounds.push_back(lf.bound);
     }
     fs.n_leaf_prims = (int)fs.prim_meta.size();
 
-    // group children (never BVH leaves): TransformedGeometry<Rectangle> records
+    // boundary prims of the general media (never BVH leaves)
     for (size_t k = 0; k < final_order.size(); ++k) {
         const Leaf &lf = leaves[final_order[k]];
-        if (!lf.is_group) continue;
-        fs.prim_meta[k].aux = (uint32_t)fs.prim_meta.size();
-        int kept = 0;
-        for (const CubeFace &f : lf.faces) {
-            double Minv[16];
-            if (!mat4_inversed(f.M, Minv)) continue;
+        if ((lf.meta.kind & 0xFFu) != RT_PRIM_MEDIUM_C) continue;
+        fs.prim_geo[k].g[1] = (double)fs.prim_meta.size();
+        fs.prim_geo[k].g[2] = (double)lf.boundary.size();
+        for (const Shape &sh : lf.boundary) {
             RtPrimMeta c{};
-            c.kind = RT_PRIM_RECT_M;
+            c.kind = sh.kind;
             c.material = RT_NO_MATERIAL;
+            c.xform = push_chain(fs, sh.chain);
+            fl.finish_meta(&c, sh.chain);
             RtPrimGeo cg{};
-            cg.g[0] = f.w;
-            cg.g[1] = f.h;
-            RtXform x;
-            make_xform(f.M, Minv, &x);
-            c.xform = (uint32_t)fs.xforms.size();
-            fs.xforms.push_back(x);
+            cg.g[0] = sh.a;
+            cg.g[1] = sh.b;
             fs.prim_meta.push_back(c);
             fs.prim_geo.push_back(cg);
             fs.prim_extra.push_back(RtPrimExtra{});
             fs.prim_bounds.push_back(Aabb{{0, 0, 0}, {0, 0, 0}});
-            ++kept;
         }
-        fs.prim_geo[k].g[0] = (double)kept;
     }
 
     // BVH over the non-hoisted leaves
@@ -590,7 +748,7 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
     // the material's kind rides in the prim's meta word (RtPrimMeta::kind bits 8-15)
     for (RtPrimMeta &m : fs.prim_meta) {
         const uint32_t mk = m.material == RT_NO_MATERIAL ? (uint32_t)RT_MAT_KIND_NONE : fs.materials[m.material].kind;
-        m.kind = (m.kind & 0xFFu) | (mk << 8);
+        m.kind = (m.kind & ~0xFF00u) | (mk << 8);
     }
     *out = std::move(fs);
     return RT_OK;

@@ -37,15 +37,18 @@ struct MaterialIR {
     int tex;
     double param;
 };
-enum GeometryKind { GEO_SPHERE, GEO_RECTANGLE, GEO_CUBE, GEO_MEDIUM };
+enum GeometryKind { GEO_SPHERE, GEO_RECTANGLE, GEO_CUBE, GEO_MEDIUM, GEO_BVH, GEO_TRANSFORMED };
 struct GeometryIR {
     GeometryKind kind;
-    double p[3]; // sphere: r | rectangle: w,h | cube: w,h,d | medium: density
-    int boundary;
+    double p[3];               // sphere: r | rectangle: w,h | cube: w,h,d | medium: density
+    int boundary;              // medium: boundary geometry | transformed: inner geometry
+    std::vector<int> children; // bvh: sprite ids (moved into the node, like the Vec BoundingVolumeHierarchyNode::new takes)
+    double M[16];              // transformed: TransformedGeometry::new(geometry, M)
 };
 struct SpriteIR {
     int geometry, material;
     double M[16];
+    bool owned; // listed in a GEO_BVH: not part of the world's own list any more
 };
 
 // host-side BVH node in binary64 (inspection, tests); RtNode is derived from it
@@ -57,8 +60,8 @@ struct HostNode {
 struct FlatScene {
     std::vector<HostNode> host_nodes;
     std::vector<RtNode> nodes;
-    // prims [0, n_hoisted) are scene-spanning and tested directly; [n_hoisted, n_leaf_prims)
-    // are BVH leaves; the rest are group children
+    // prims [0, n_hoisted) are scene-filling and tested directly; [n_hoisted, n_leaf_prims)
+    // are BVH leaves; the rest are the boundary prims of general media
     std::vector<RtPrimMeta> prim_meta;
     std::vector<RtPrimGeo> prim_geo;
     std::vector<RtPrimExtra> prim_extra;

@@ -122,7 +122,7 @@
 #endif
 #define RT_SWAP_CLASSES 3  /* lambertian, metal, dielectric (RT_MAT_* values 0..2) */
 #define RT_SWAP_F64 14     /* o, d, T (9), s0, s1, best_t, draws, base */
-#define RT_SWAP_F32 4      /* k, best_prim, slot, best_sub */
+#define RT_SWAP_F32 3      /* k, best_prim, slot */
 #define RT_SWAP_HDR_BYTES 32u
 #define RT_SWAP_CLASS_BYTES ((unsigned)((RT_SWAP_F64 * 8 + RT_SWAP_F32 * 4) * RT_SWAP_CAP))
 #define RT_SWAP_LDS_BYTES (RT_SWAP_HDR_BYTES + RT_SWAP_CLASSES * RT_SWAP_CLASS_BYTES)
@@ -142,10 +142,10 @@ struct LdsStack {
     }
 };
 // workgroup size and waves per SIMD of each kernel family
-__host__ __device__ constexpr int block_of(bool general, bool medium) {
+__host__ __device__ constexpr int block_of(bool general, int medium) {
     return general ? (medium ? RT_BLOCK_GENERAL : RT_BLOCK_LEAN) : RT_BLOCK;
 }
-__host__ __device__ constexpr int waves_of(bool general, bool medium) {
+__host__ __device__ constexpr int waves_of(bool general, int medium) {
     return general ? (medium ? RT_WAVES_PER_EU_GENERAL : RT_WAVES_PER_EU_LEAN) : RT_WAVES_PER_EU;
 }
 
@@ -159,7 +159,7 @@ __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__bui
 // in ~1/4 of an L2 hit.
 extern __shared__ __attribute__((aligned(16))) unsigned char rt_lds[];
 
-template <bool GENERAL, bool MEDIUM, bool TEXTURED, bool LENS, bool COUNT, bool LDSNODES, bool SWAP>
+template <bool GENERAL, int MEDIUM, bool TEXTURED, bool LENS, bool COUNT, bool LDSNODES, bool SWAP>
 __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM)) void render_kernel(const RtLaunch L) {
     constexpr int kBlock = block_of(GENERAL, MEDIUM);
     uint32_t *stack_mem = reinterpret_cast<uint32_t *>(rt_lds);
@@ -186,7 +186,6 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
     tv.cur = RT_CUR_DONE;
     tv.sp = 0;
     tv.best_prim = 0xFFFFFFFFu;
-    tv.best_sub = 0u;
     tv.best_t = 0.0;
     bool has_path = false;
     uint32_t slot = 0; // index of this lane's sample in L.samples
@@ -362,7 +361,6 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                         f32[0 * RT_SWAP_CAP] = (uint32_t)ps.k;
                         f32[1 * RT_SWAP_CAP] = tv.best_prim;
                         f32[2 * RT_SWAP_CAP] = slot;
-                        if (GENERAL) f32[3 * RT_SWAP_CAP] = tv.best_sub;
                         has_path = false;
                         cls = kEmpty;
                         if (COUNT) ++w_park;
@@ -400,7 +398,6 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                             ps.k = (int32_t)f32[0 * RT_SWAP_CAP];
                             tv.best_prim = f32[1 * RT_SWAP_CAP];
                             slot = f32[2 * RT_SWAP_CAP];
-                            if (GENERAL) tv.best_sub = f32[3 * RT_SWAP_CAP];
                             tv.cur = RT_CUR_DONE;
                             tv.sp = 0;
                             has_path = true;
@@ -655,7 +652,7 @@ __global__ void probe_math_kernel(const double *a, const double *b, int n, doubl
 // ---- dispatch over the template instantiations ----
 typedef void (*KernelFn)(const RtLaunch);
 
-template <bool GENERAL, bool MEDIUM, bool TEXTURED, bool SWAP>
+template <bool GENERAL, int MEDIUM, bool TEXTURED, bool SWAP>
 KernelFn pick3(bool lens, bool count, bool ldsnodes) {
 #define RT_PICK(LN, C, LD) return render_kernel<GENERAL, MEDIUM, TEXTURED, LN, C, LD, SWAP>
     if (lens) {
@@ -677,16 +674,18 @@ KernelFn pick3(bool lens, bool count, bool ldsnodes) {
 KernelFn pick(unsigned features, bool lens, bool count, int lds_mode) {
     const bool ldsnodes = (lds_mode & 1) != 0, swap = (lds_mode & 2) != 0;
     // general prims only (matrices, rectangles, cubes: the Cornell box): no medium / texture code in the kernel
-    if (features == 1u) return swap ? pick3<true, false, false, true>(lens, count, ldsnodes) : pick3<true, false, false, false>(lens, count, ldsnodes);
-    if (features != 0u) return swap ? pick3<true, true, true, true>(lens, count, ldsnodes) : pick3<true, true, true, false>(lens, count, ldsnodes);
-    return swap ? pick3<false, false, false, true>(lens, count, ldsnodes) : pick3<false, false, false, false>(lens, count, ldsnodes);
+    if (features == 1u) return swap ? pick3<true, 0, false, true>(lens, count, ldsnodes) : pick3<true, 0, false, false>(lens, count, ldsnodes);
+    // media over a general boundary (bit 8): the kernel with medium_general_hit; else the one with sphere media only
+    if (features & 8u) return swap ? pick3<true, 2, true, true>(lens, count, ldsnodes) : pick3<true, 2, true, false>(lens, count, ldsnodes);
+    if (features != 0u) return swap ? pick3<true, 1, true, true>(lens, count, ldsnodes) : pick3<true, 1, true, false>(lens, count, ldsnodes);
+    return swap ? pick3<false, 0, false, true>(lens, count, ldsnodes) : pick3<false, 0, false, false>(lens, count, ldsnodes);
 }
 
 } // namespace
 
 extern "C" int rt_kernel_block_size(unsigned features);
 
-// feature bits: 1 = general prims, 2 = media, 4 = textured.  `blocks` persistent workgroups,
+// feature bits: 1 = general prims, 2 = media, 4 = textured, 8 = media over a general boundary.  `blocks` persistent workgroups,
 // `lds_bytes` of dynamic LDS (stack + optional node copy).
 extern "C" int rt_launch_render(const RtLaunch *L, unsigned features, int lens, int count, int ldsnodes, int blocks,
                                 unsigned lds_bytes, void *stream) {

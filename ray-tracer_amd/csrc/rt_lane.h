@@ -65,7 +65,6 @@ struct Rec { // HitRecord, src/ray.rs:36-43 (material lives on the prim)
     double t;
     V3 p, n;
     double u, v;
-    uint32_t sub; // which face of a cube produced the hit (lets the shade step rebuild only that face)
 };
 
 // ---- per-sample random numbers: include/rt_rng.h ----
@@ -174,9 +173,9 @@ RT_HD void sphere_uv(V3 q, double *u, double *v) { // unitSphereUv, src/geometry
     *u = 0.5 + atan2(q.x, q.z) / (2.0 * RTL_PI);
     *v = 1.0 - acos(q.y) / RTL_PI;
 }
-// full local record for a known t (src/geometry.rs:66-71)
-template <bool UV>
-RT_HD void sphere_finish(V3 oc, V3 d, double radius, double t, Rec *r) {
+// full local record for a known t (src/geometry.rs:66-71).  uv: the reference evaluates atan2 / acos on every hit; they
+// only ever reach Texture::value, so they are computed when the hit material's texture reads them (checker / image)
+RT_HD void sphere_finish(V3 oc, V3 d, double radius, double t, bool uv, Rec *r) {
     V3 p = oc + d * t;
     V3 q = p / radius;
     r->t = t;
@@ -184,7 +183,7 @@ RT_HD void sphere_finish(V3 oc, V3 d, double radius, double t, Rec *r) {
     r->n = normalized(q);
     r->u = 0.0;
     r->v = 0.0;
-    if (UV) sphere_uv(q, &r->u, &r->v);
+    if (uv) sphere_uv(q, &r->u, &r->v);
 }
 
 // ---- Rectangle::hit, local frame (src/geometry.rs:153-180) ----
@@ -210,20 +209,19 @@ RT_HD void to_world(const RtXform &x, Rec *r) {
 }
 
 // ---- ConstantMedium<Sphere>::hit, boundary frame (src/volume.rs:46-100) ----
-template <bool UV>
 RT_HD bool medium_hit(V3 oc, V3 d, double radius, double density, uint64_t rng_base, uint32_t segment, uint32_t slot,
-                      unsigned long long *draws, Rec *r) {
+                      unsigned long long *draws, bool uv, Rec *r) {
     double a = dot(d, d);
     double t1;
     if (!sphere_t(oc, d, a, radius, &t1)) return false;
     Rec r1;
-    sphere_finish<UV>(oc, d, radius, t1, &r1);
+    sphere_finish(oc, d, radius, t1, uv, &r1);
     if (dot(r1.n, d) < 0.0) {
         V3 o2 = r1.p + d * 1e-6; // restarted ray
         double t2;
         if (!sphere_t(o2, d, a, radius, &t2)) return false;
         Rec r2;
-        sphere_finish<UV>(o2, d, radius, t2, &r2);
+        sphere_finish(o2, d, radius, t2, uv, &r2);
         double inside = r2.t;
         ++*draws;
         double distance = (-1.0 / density) * log(rt_u64_to_range01(rt_rng_keyed_from_base(rng_base, segment, slot)));
@@ -254,16 +252,125 @@ struct SegCtx { // what a primitive test may need besides the ray
     unsigned long long prims_tested;
 };
 
+// ---- transform chains: Sprite::hit / TransformedGeometry::hit level by level (src/sprite.rs:101-126, src/geometry.rs:220-236)
+// A level that is a pure translation by t (bit RT_META_TMASK_SHIFT + i of the meta word) contributes only its offsets:
+// M^-1 (o,1) = o + inv_t, M^-1 (d,0) = d, M (p,1) = p + t, M (n,0) = n -- the values the 4x4 products give for it.
+// (constant trip counts: the compiler unrolls them, and a level the wave does not have is one skipped branch; a
+// data-dependent loop here made it keep the hit record in scratch memory)
+RT_HD void chain_down(const RtLaunch &L, uint32_t first, uint32_t len, uint32_t tmask, V3 *o, V3 *d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t i = 0; i < (uint32_t)RT_MAX_CHAIN; ++i) {
+        if (i >= len) continue;
+        const RtXform &X = L.xforms[first + i];
+        if ((tmask >> i) & 1u) {
+            *o = mk(o->x + X.inv[3], o->y + X.inv[7], o->z + X.inv[11]);
+        } else {
+            const V3 lo = xf_point(X.inv, *o);
+            *d = xf_vector(X.inv, *d); // not renormalised (quirk Q5)
+            *o = lo;
+        }
+    }
+}
+RT_HD void chain_up(const RtLaunch &L, uint32_t first, uint32_t len, uint32_t tmask, Rec *r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t k = 0; k < (uint32_t)RT_MAX_CHAIN; ++k) {
+        const uint32_t i = (uint32_t)RT_MAX_CHAIN - 1u - k;
+        if (i >= len) continue;
+        const RtXform &X = L.xforms[first + i];
+        if ((tmask >> i) & 1u)
+            r->p = mk(r->p.x + X.m[3], r->p.y + X.m[7], r->p.z + X.m[11]);
+        else
+            to_world(X, r);
+    }
+}
+
+// sphere / rectangle in its own frame.  RECORD = false: only r->t is meaningful
+template <bool RECORD>
+RT_HD bool shape_hit(uint32_t kind, const RtPrimGeo &G, V3 lo, V3 ld, bool uv, Rec *r) {
+    if (kind == RT_PRIM_SPHERE_C) {
+        const double la = dot(ld, ld);
+        double t;
+        if (!sphere_t(lo, ld, la, G.g[0], &t)) return false;
+        r->t = t;
+        if (RECORD) sphere_finish(lo, ld, G.g[0], t, uv, r);
+        return true;
+    }
+    return rect_hit(lo, ld, G.g[0], G.g[1], r); // RT_PRIM_RECT_C
+}
+
+// ---- ConstantMedium<T: Hit>::hit over any boundary (src/volume.rs:40-100): the boundary's spheres / rectangles
+// prims [first, first + count), each under its own chain below the medium; boundary.hit = their nearest hit,
+// strict <, the earlier one wins ties (src/geometry.rs:76-116, src/optimize.rs:469-498)
+RT_HD bool medium_general_hit(const RtLaunch &L, const RtPrimGeo &G, V3 o, V3 d, uint64_t rng_base, uint32_t segment, uint32_t slot,
+                              unsigned long long *draws, unsigned long long *tests, bool uv, Rec *r) {
+    const double density = G.g[0];
+    const uint32_t first = (uint32_t)G.g[1], count = (uint32_t)G.g[2];
+    Rec r1, r2;
+    V3 ro = o;
+    for (int pass = 0; pass < 2; ++pass) { // boundary.hit(ray), then boundary.hit(restarted ray)
+        Rec best;
+        bool have = false;
+        for (uint32_t k = 0; k < count; ++k) {
+            const uint32_t ci = first + k;
+            const uint32_t kw = L.prim_meta[ci].kind;
+            const uint32_t cf = L.prim_meta[ci].xform, cl = (kw >> RT_META_CHAIN_SHIFT) & 7u, cm = (kw >> RT_META_TMASK_SHIFT) & 0xFu;
+            V3 co = ro, cd = d;
+            chain_down(L, cf, cl, cm, &co, &cd);
+            Rec cr;
+            ++*tests;
+            if (shape_hit<true>(kw & 0xFFu, L.prim_geo[ci], co, cd, uv, &cr) && (!have || cr.t < best.t)) {
+                chain_up(L, cf, cl, cm, &cr);
+                best = cr;
+                have = true;
+            }
+        }
+        if (!have) return false;
+        if (pass == 0) {
+            r1 = best;
+            if (!(dot(r1.n, d) < 0.0)) break;  // the origin is inside the boundary
+            ro = r1.p + d * 1e-6;               // restarted ray
+        } else {
+            r2 = best;
+        }
+    }
+    if (dot(r1.n, d) < 0.0) {
+        const double inside = r2.t;
+        ++*draws;
+        const double distance = (-1.0 / density) * log(rt_u64_to_range01(rt_rng_keyed_from_base(rng_base, segment, slot)));
+        if (distance > inside) return false;
+        r->u = r1.u + r2.u;
+        r->v = r1.v + r2.v;
+        r->t = r1.t + distance;
+        r->p = ro + d * (r1.t + distance); // on the restarted ray (quirk Q9)
+        r->n = (r1.n + r2.n) / 2.0;
+        return true;
+    }
+    const double inside = r1.t;
+    ++*draws;
+    const double distance = (-1.0 / density) * log(rt_u64_to_range01(rt_rng_keyed_from_base(rng_base, segment, slot)));
+    if (distance > inside) return false;
+    r->u = r1.u;
+    r->v = r1.v;
+    r->t = distance;
+    r->p = o + d * distance;
+    r->n = r1.n;
+    return true;
+}
+
 // Intersect primitive `pi` with the world ray; on a hit fill the world-space record.
-// RECORD = false: only r->t is meaningful (traversal); true: full record (shading).
-// only_face: RT_ALL_FACES, or the one cube face to evaluate (the winner found during traversal).
-#define RT_ALL_FACES 0xFFFFFFFFu
-template <bool GENERAL, bool MEDIUM, bool UV, bool RECORD>
-RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx &sc, Rec *r, uint32_t only_face = RT_ALL_FACES) {
+// RECORD = false: only r->t is meaningful (traversal); true: full record (shading), uv when `uv`.
+// MEDIUM: 0 no media in the scene, 1 only ConstantMedium<Sphere> sprites under a pure translation (RT_PRIM_MEDIUM_T,
+// the reference's own scenes), 2 media over any boundary (RT_PRIM_MEDIUM_C) as well.
+template <bool GENERAL, int MEDIUM, bool RECORD>
+RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx &sc, Rec *r, bool uv) {
     const RtPrimGeo &G = L.prim_geo[pi];
-    r->sub = 0u;
-    uint32_t kind = (uint32_t)RT_PRIM_SPHERE_T;
-    if (GENERAL || MEDIUM) kind = L.prim_meta[pi].kind & 0xFFu; // bits 8-15 carry the material's kind
+    uint32_t kw = (uint32_t)RT_PRIM_SPHERE_T;
+    if (GENERAL || MEDIUM) kw = L.prim_meta[pi].kind; // bits 8-15 carry the material's kind, 16-23 the chain
+    const uint32_t kind = kw & 0xFFu;
     ++sc.prims_tested;
     if (kind == RT_PRIM_SPHERE_T) {
         // Sprite::hit with a translation matrix: M^-1 (o,1) = o - c, M^-1 (d,0) = d,
@@ -274,7 +381,7 @@ RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx
         if (!sphere_t(oc, d, a, G.g[3], &t)) return false;
         r->t = t;
         if (RECORD) {
-            sphere_finish<UV>(oc, d, G.g[3], t, r);
+            sphere_finish(oc, d, G.g[3], t, uv, r);
             r->p = r->p + c;
         }
         return true;
@@ -283,50 +390,20 @@ RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx
         const RtPrimMeta &P = L.prim_meta[pi];
         if (MEDIUM && kind == RT_PRIM_MEDIUM_T) {
             V3 c = mk(G.g[0], G.g[1], G.g[2]);
-            if (!medium_hit<UV>(o - c, d, G.g[3], L.prim_extra[pi].e[0], sc.rng_base, sc.segment, P.aux, &sc.draws, r)) return false;
+            if (!medium_hit(o - c, d, G.g[3], L.prim_extra[pi].e[0], sc.rng_base, sc.segment, P.aux, &sc.draws, uv, r)) return false;
             if (RECORD) r->p = r->p + c;
             return true;
         }
-        const RtXform &X = L.xforms[P.xform];
-        V3 lo = xf_point(X.inv, o);
-        V3 ld = xf_vector(X.inv, d); // not renormalised (quirk Q5)
-        bool ok = false;
-        if (kind == RT_PRIM_SPHERE_M) {
-            double la = dot(ld, ld);
-            double t;
-            if (sphere_t(lo, ld, la, G.g[0], &t)) {
-                ok = true;
-                r->t = t;
-                if (RECORD) sphere_finish<UV>(lo, ld, G.g[0], t, r);
-            }
-        } else if (kind == RT_PRIM_RECT_M) {
-            ok = rect_hit(lo, ld, G.g[0], G.g[1], r);
-        } else if (kind == RT_PRIM_GROUP_M) {
-            // BoundingVolumeHierarchyNode over the faces (src/optimize.rs:469-498):
-            // nearest face, strict <, first face wins ties; the boxes only filter
-            const uint32_t first = P.aux, count = (uint32_t)G.g[0];
-            double best = RTL_INF;
-            const uint32_t k0 = only_face == RT_ALL_FACES ? 0u : only_face, k1 = only_face == RT_ALL_FACES ? count : only_face + 1u;
-            for (uint32_t k = k0; k < k1; ++k) {
-                const RtPrimGeo &CG = L.prim_geo[first + k];
-                const RtXform &CX = L.xforms[L.prim_meta[first + k].xform];
-                V3 co = xf_point(CX.inv, lo);
-                V3 cd = xf_vector(CX.inv, ld);
-                Rec cr;
-                ++sc.prims_tested;
-                if (rect_hit(co, cd, CG.g[0], CG.g[1], &cr) && cr.t < best) {
-                    best = cr.t;
-                    if (RECORD) to_world(CX, &cr); // TransformedGeometry::hit, src/geometry.rs:228-236
-                    *r = cr;
-                    r->sub = k;
-                    ok = true;
-                }
-            }
-        } else if (MEDIUM && kind == RT_PRIM_MEDIUM_M) {
-            ok = medium_hit<UV>(lo, ld, G.g[0], G.g[1], sc.rng_base, sc.segment, P.aux, &sc.draws, r);
-        }
+        const uint32_t first = P.xform, len = (kw >> RT_META_CHAIN_SHIFT) & 7u, tmask = (kw >> RT_META_TMASK_SHIFT) & 0xFu;
+        V3 lo = o, ld = d;
+        chain_down(L, first, len, tmask, &lo, &ld);
+        bool ok;
+        if (MEDIUM >= 2 && kind == RT_PRIM_MEDIUM_C)
+            ok = medium_general_hit(L, G, lo, ld, sc.rng_base, sc.segment, P.aux, &sc.draws, &sc.prims_tested, uv, r);
+        else
+            ok = shape_hit<RECORD>(kind, G, lo, ld, uv, r);
         if (!ok) return false;
-        if (RECORD) to_world(X, r);
+        if (RECORD) chain_up(L, first, len, tmask, r);
         return true;
     }
     return false;
@@ -345,11 +422,13 @@ struct Trav {
     int32_t sp;          // stack pointer (entries live in the Stack policy object)
     double best_t;
     uint32_t best_prim;
-    uint32_t best_sub;   // winning cube face (general scenes)
     float best32;        // best_t rounded up to binary32
     float idx, idy, idz; // 1 / d
     float nx, ny, nz;    // -(o/d + pad): entry planes,  t = plane * id + n
     float fx, fy, fz;    // -(o/d - pad): exit planes
+    uint32_t ox, oy, oz; // byte offset inside an RtNode of the (child0, child1) pair of the plane the ray ENTERS through on
+                         // each axis (lo_* for a positive direction, hi_* for a negative one); the exit pair is at
+                         // ox ^ 24, oy ^ 40, oz ^ 56
 };
 
 RT_HD float up32(double t) { // >= t in binary32, with room for the ~3e-7 relative error of a computed tnear
@@ -398,7 +477,7 @@ RT_HD void trav_pop(Trav &tv, Stack &st) {
 }
 
 // start a segment: binary32 ray constants, hoisted prims, root
-template <bool GENERAL, bool MEDIUM, bool UV, class Stack>
+template <bool GENERAL, int MEDIUM, class Stack>
 RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack &st) {
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
     tv.idx = rcp32((float)d.x);
@@ -415,17 +494,19 @@ RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack
     tv.fx = -(qx - ex);
     tv.fy = -(qy - ey);
     tv.fz = -(qz - ez);
+    // sign bit of 1/d picks the entry plane of each axis (an infinite or NaN reciprocal only ever removes constraints)
+    tv.ox = (f32_bits(tv.idx) >> 31) * 24u;
+    tv.oy = (f32_bits(tv.idy) >> 31) * 24u + 8u;
+    tv.oz = (f32_bits(tv.idz) >> 31) * 24u + 16u;
     tv.best_t = RTL_INF;
     tv.best_prim = 0xFFFFFFFFu;
-    tv.best_sub = 0u;
     const double a = dot(d, d);
     for (int32_t pi = 0; pi < L.n_hoisted; ++pi) {
         Rec r;
-        if (prim_hit<GENERAL, MEDIUM, UV, false>(L, (uint32_t)pi, o, d, a, sc, &r)) {
+        if (prim_hit<GENERAL, MEDIUM, false>(L, (uint32_t)pi, o, d, a, sc, &r, false)) {
             if (r.t < tv.best_t) { // ascending prim id: ties keep the lower id
                 tv.best_t = r.t;
                 tv.best_prim = (uint32_t)pi;
-                if (GENERAL) tv.best_sub = r.sub;
             }
         }
     }
@@ -434,32 +515,39 @@ RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack
     tv.cur = L.root;
 }
 
-// one inner-node step (tv.cur is an inner node reference).  `nodes` is the node array
-// (LDS copy or global).  Branch-free up to the push/pop so the whole 64-byte node,
-// child references included, is fetched by one batch of loads.
+// one inner-node step (tv.cur is an inner node reference).  `nodes` is the node array (LDS copy or global).
+// Slab test of BOTH children: per axis the ray's entry plane and exit plane are read as (child0, child1) pairs through
+// the per-ray offsets tv.ox/oy/oz -- 12 fused multiply-adds and two max3 / min3 per node instead of testing all four
+// plane combinations and sorting them with min / max (v_min_f32 / v_max_f32 issue at half the rate of v_fma_f32 on
+// gfx950, profiles/r02_valu_issue.json).  Branch-free up to the push/pop.
+struct F2 {
+    float a, b;
+};
+RT_HD F2 ld_pair(const RtNode *n, uint32_t byte_off) {
+    const float *p = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(n) + byte_off);
+    F2 r;
+    r.a = p[0];
+    r.b = p[1];
+    return r;
+}
 template <class Stack>
 RT_HD void trav_node_step(const RtNode *nodes, Trav &tv, Stack &st) {
-    const RtNode &N = nodes[tv.cur];
-    const uint32_t c0 = N.child[0], c1 = N.child[1];
-    float tmin[2], tmax[2];
-    for (int c = 0; c < 2; ++c) {
-        // fminf / fmaxf ignore a NaN operand (0 * inf planes), like the reference's selects
-        const float ax = fmaf(N.lo_x[c], tv.idx, tv.nx), bx = fmaf(N.hi_x[c], tv.idx, tv.nx);
-        const float ay = fmaf(N.lo_y[c], tv.idy, tv.ny), by = fmaf(N.hi_y[c], tv.idy, tv.ny);
-        const float az = fmaf(N.lo_z[c], tv.idz, tv.nz), bz = fmaf(N.hi_z[c], tv.idz, tv.nz);
-        const float cx = fmaf(N.lo_x[c], tv.idx, tv.fx), dx = fmaf(N.hi_x[c], tv.idx, tv.fx);
-        const float cy = fmaf(N.lo_y[c], tv.idy, tv.fy), dy = fmaf(N.hi_y[c], tv.idy, tv.fy);
-        const float cz = fmaf(N.lo_z[c], tv.idz, tv.fz), dz = fmaf(N.hi_z[c], tv.idz, tv.fz);
-        tmin[c] = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-        tmax[c] = fminf(fminf(fmaxf(cx, dx), fmaxf(cy, dy)), fminf(fmaxf(cz, dz), tv.best32));
-    }
+    const RtNode *N = &nodes[tv.cur];
+    const F2 px = ld_pair(N, tv.ox), py = ld_pair(N, tv.oy), pz = ld_pair(N, tv.oz);                   // entry planes
+    const F2 qx = ld_pair(N, tv.ox ^ 24u), qy = ld_pair(N, tv.oy ^ 40u), qz = ld_pair(N, tv.oz ^ 56u); // exit planes
+    const uint32_t c0 = N->child[0], c1 = N->child[1];
+    // fminf / fmaxf ignore a NaN operand (0 * inf planes), like the reference's selects: such an axis drops out
+    const float tmin0 = fmaxf(fmaxf(fmaf(px.a, tv.idx, tv.nx), fmaf(py.a, tv.idy, tv.ny)), fmaxf(fmaf(pz.a, tv.idz, tv.nz), 0.0f));
+    const float tmin1 = fmaxf(fmaxf(fmaf(px.b, tv.idx, tv.nx), fmaf(py.b, tv.idy, tv.ny)), fmaxf(fmaf(pz.b, tv.idz, tv.nz), 0.0f));
+    const float tmax0 = fminf(fminf(fmaf(qx.a, tv.idx, tv.fx), fmaf(qy.a, tv.idy, tv.fy)), fminf(fmaf(qz.a, tv.idz, tv.fz), tv.best32));
+    const float tmax1 = fminf(fminf(fmaf(qx.b, tv.idx, tv.fx), fmaf(qy.b, tv.idy, tv.fy)), fminf(fmaf(qz.b, tv.idz, tv.fz), tv.best32));
     // slack for the rounding of the slab arithmetic itself
-    const bool h0 = tmin[0] <= tmax[0] * 1.000002f, h1 = tmin[1] <= tmax[1] * 1.000002f;
-    const bool one_first = tmin[1] < tmin[0];
+    const bool h0 = tmin0 <= tmax0 * 1.000002f, h1 = tmin1 <= tmax1 * 1.000002f;
+    const bool one_first = tmin1 < tmin0;
     const bool both = h0 && h1;
     const uint32_t first = both ? (one_first ? c1 : c0) : (h0 ? c0 : c1);
     const uint32_t second = one_first ? c0 : c1;
-    const float second_t = one_first ? tmin[0] : tmin[1];
+    const float second_t = one_first ? tmin0 : tmin1;
     if (both) st.push(tv.sp, (f32_bits(second_t) & 0xFFFF0000u) | second);
     if (h0 || h1)
         tv.cur = first;
@@ -468,17 +556,16 @@ RT_HD void trav_node_step(const RtNode *nodes, Trav &tv, Stack &st) {
 }
 
 // one leaf step (tv.cur is a leaf reference): binary64 primitive test, then pop
-template <bool GENERAL, bool MEDIUM, bool UV, class Stack>
+template <bool GENERAL, int MEDIUM, class Stack>
 RT_HD void trav_leaf_step(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack &st) {
     const uint32_t pi = tv.cur & RT_REF_MAX;
     const double a = dot(d, d);
     Rec r;
-    if (prim_hit<GENERAL, MEDIUM, UV, false>(L, pi, o, d, a, sc, &r)) {
+    if (prim_hit<GENERAL, MEDIUM, false>(L, pi, o, d, a, sc, &r, false)) {
         // nearest t; exact ties go to the lower prim id, whatever the visiting order
         if (r.t < tv.best_t || (r.t == tv.best_t && pi < tv.best_prim)) {
             tv.best_t = r.t;
             tv.best_prim = pi;
-            if (GENERAL) tv.best_sub = r.sub;
             tv.best32 = up32(r.t);
         }
     }
@@ -633,26 +720,26 @@ RT_HD void start_sample(const RtLaunch &L, uint32_t x, uint32_t y, uint32_t s, P
     ps->k = 0;
 }
 
-template <bool GENERAL, bool MEDIUM, bool TEXTURED, class Stack>
+template <bool GENERAL, int MEDIUM, bool TEXTURED, class Stack>
 RT_HD void begin_segment(const RtLaunch &L, PathState *ps, Trav &tv, Stack &st, unsigned long long *prims_tested) {
     SegCtx sc;
     sc.rng_base = ps->g.base;
     sc.segment = (uint32_t)ps->k;
     sc.draws = 0;
     sc.prims_tested = 0;
-    trav_begin<GENERAL, MEDIUM, TEXTURED>(L, ps->o, ps->d, sc, tv, st);
+    trav_begin<GENERAL, MEDIUM>(L, ps->o, ps->d, sc, tv, st);
     ps->g.draws += sc.draws;
     *prims_tested += sc.prims_tested;
 }
 
-template <bool GENERAL, bool MEDIUM, bool TEXTURED, class Stack>
+template <bool GENERAL, int MEDIUM, bool TEXTURED, class Stack>
 RT_HD void leaf_step(const RtLaunch &L, PathState *ps, Trav &tv, Stack &st, unsigned long long *prims_tested) {
     SegCtx sc;
     sc.rng_base = ps->g.base;
     sc.segment = (uint32_t)ps->k;
     sc.draws = 0;
     sc.prims_tested = 0;
-    trav_leaf_step<GENERAL, MEDIUM, TEXTURED>(L, ps->o, ps->d, sc, tv, st);
+    trav_leaf_step<GENERAL, MEDIUM>(L, ps->o, ps->d, sc, tv, st);
     ps->g.draws += sc.draws;
     *prims_tested += sc.prims_tested;
 }
@@ -663,14 +750,16 @@ RT_HD void leaf_step(const RtLaunch &L, PathState *ps, Trav &tv, Stack &st, unsi
 // radiance in *radiance.
 // ball_iters > 0 bounds the rejection sampler of this call; when the bound is hit *pending is set, nothing but the
 // stream has advanced and the same hit has to be finished again (the kernel does so in its next shade block).
-template <bool GENERAL, bool MEDIUM, bool TEXTURED>
+template <bool GENERAL, int MEDIUM, bool TEXTURED>
 RT_HD bool finish_segment(const RtLaunch &L, PathState *ps, const Trav &tv, V3 *radiance, int ball_iters = 0, bool *pending = nullptr) {
-    constexpr bool UV = TEXTURED;
     *radiance = mk(0.0, 0.0, 0.0);
     if (tv.best_prim == 0xFFFFFFFFu) return true; // background is black (src/render.rs:21-28)
     const uint32_t prim = tv.best_prim;
     const uint32_t mat = L.prim_meta[prim].material;
     if (mat == RT_NO_MATERIAL) return true; // src/render.rs:18-20
+    const RtMaterial &M = L.materials[mat];
+    // uv feeds nothing but Texture::value (src/material.rs:196-198): needed iff the material's texture is not a solid colour
+    const bool uv = TEXTURED && !M.solid;
     Rec rec;
     if (GENERAL || MEDIUM) {
         SegCtx sc;
@@ -678,16 +767,15 @@ RT_HD bool finish_segment(const RtLaunch &L, PathState *ps, const Trav &tv, V3 *
         sc.segment = (uint32_t)ps->k;
         sc.draws = 0;
         sc.prims_tested = 0;
-        // rebuild the record of the winner; for a cube only its winning face (same arithmetic, same t)
-        prim_hit<GENERAL, MEDIUM, UV, true>(L, prim, ps->o, ps->d, dot(ps->d, ps->d), sc, &rec, tv.best_sub);
+        // rebuild the full record of the winner (same arithmetic, same t, same keyed draws)
+        prim_hit<GENERAL, MEDIUM, true>(L, prim, ps->o, ps->d, dot(ps->d, ps->d), sc, &rec, uv);
     } else {
         const RtPrimGeo &G = L.prim_geo[prim];
         V3 c = mk(G.g[0], G.g[1], G.g[2]);
-        sphere_finish<UV>(ps->o - c, ps->d, G.g[3], tv.best_t, &rec);
+        sphere_finish(ps->o - c, ps->d, G.g[3], tv.best_t, uv, &rec);
         rec.p = rec.p + c;
     }
     V3 o2, d2, att, emit;
-    const RtMaterial &M = L.materials[mat];
     bool pend = false;
     const bool cont = shade<TEXTURED>(L, M, rec, ps->d, ps->g, &o2, &d2, &att, &emit, ball_iters, &pend);
     if (pend) {

@@ -9,7 +9,8 @@
 #define RT_TILE_EDGE 8
 #define RT_TILE_PIXELS 64
 #define RT_STACK_DEPTH 24   /* traversal stack entries per lane; the builder bounds the tree depth to this */
-#define RT_MAX_HOISTED 4    /* scene-spanning prims tested up front instead of through the BVH */
+#define RT_MAX_HOISTED 4    /* scene-filling prims tested up front instead of through the BVH */
+#define RT_MAX_CHAIN 4      /* transform levels above one leaf (Sprite > BVH > Sprite > TransformedGeometry ...) */
 #define RT_JOB_SPP_MAX 32   /* samples per pixel in one job at most (job = one 8x8 tile x job_spp samples) */
 #define RT_NO_MATERIAL 0xFFFFFFFFu
 #define RT_MAT_KIND_NONE 0xFFu /* in RtPrimMeta::kind bits 8-15: the prim has no material */
@@ -20,15 +21,26 @@
 #define RT_CUR_DONE 0x10000u      /* traversal finished, lane waits for the shade block */
 #define RT_CUR_DEAD 0x20000u      /* no work left for this lane */
 
-// primitive kinds (leaves of the acceleration structure)
+// primitive kinds (leaves of the acceleration structure).  Every leaf is ONE sphere, rectangle or medium under a
+// chain of up to RT_MAX_CHAIN transforms (outermost first): a Sprite whose geometry is a BoundingVolumeHierarchyNode of
+// further sprites / TransformedGeometry (src/sprite.rs:87-93, src/optimize.rs:339-343) is expanded at commit, each of
+// its leaves keeping the transforms of every level -- Cube::new's six faces (src/geometry.rs:254-286) become six
+// rectangle leaves with the chain {sprite matrix, face matrix}.  The ray goes down the chain matrix by matrix and the
+// hit record comes back up it, in the reference's arithmetic (src/sprite.rs:101-126 at every level).
 enum RtPrimKind : uint32_t {
-    RT_PRIM_SPHERE_T = 0, // Sprite<Sphere> whose transform is a pure translation: geo = {cx, cy, cz, r}
-    RT_PRIM_SPHERE_M = 1, // Sprite<Sphere>, general matrix: geo = {r}, xform
-    RT_PRIM_RECT_M = 2,   // Sprite<Rectangle> / TransformedGeometry<Rectangle>: geo = {w, h}, xform
-    RT_PRIM_GROUP_M = 3,  // Sprite<BVH of TransformedGeometry<Rectangle>> (Cube): aux = first child, geo[0] = count, xform
-    RT_PRIM_MEDIUM_T = 4, // Sprite<ConstantMedium<Sphere>>, translation: geo = {cx, cy, cz, r}, extra = {density}, aux = rng slot
-    RT_PRIM_MEDIUM_M = 5, // general matrix: geo = {r, density}, xform, aux = rng slot
+    RT_PRIM_SPHERE_T = 0, // Sprite<Sphere> whose only transform is a pure translation: geo = {cx, cy, cz, r}, no chain
+    RT_PRIM_SPHERE_C = 1, // sphere under a chain: geo = {r}
+    RT_PRIM_RECT_C = 2,   // rectangle under a chain: geo = {w, h}
+    RT_PRIM_MEDIUM_T = 4, // Sprite<ConstantMedium<Sphere>>, pure translation: geo = {cx, cy, cz, r}, extra = {density}, aux = rng key
+    RT_PRIM_MEDIUM_C = 5, // ConstantMedium<any boundary> under a chain: geo = {density, first boundary prim, count}, aux = rng key;
+                          // the boundary's prims (spheres / rectangles with their own chains below the medium) follow the
+                          // leaf prims in the prim arrays and are never BVH leaves
 };
+// RtPrimMeta::kind: bits 0-7 RT_PRIM_*, bits 8-15 kind of the material (RT_MAT_*, RT_MAT_KIND_NONE), bits 16-18 chain
+// length, bits 20-23 one bit per chain level: that level is a pure translation (only its offset is used:
+// o' = o + inv_t, d' = d, p = p' + t, n = n' -- what the 4x4 products give for such a matrix, rounding for rounding)
+#define RT_META_CHAIN_SHIFT 16
+#define RT_META_TMASK_SHIFT 20
 
 enum RtMaterialKind : uint32_t {
     RT_MAT_LAMBERTIAN = 0,
@@ -51,11 +63,10 @@ struct alignas(16) RtNode {
 }; // 64 B
 
 struct alignas(16) RtPrimMeta {
-    uint32_t kind;     // bits 0-7: RT_PRIM_*; bits 8-15: kind of its material (RT_MAT_*, RT_MAT_KIND_NONE without one), so
-                       // the shade block classifies a hit with one load
+    uint32_t kind;     // see RT_META_*: prim kind, material kind (the shade block classifies a hit with one load), chain
     uint32_t material; // RT_NO_MATERIAL = the reference's `material: None`
-    uint32_t xform;    // index into xforms (kinds *_M)
-    uint32_t aux;      // GROUP: first child prim; MEDIUM: rng slot
+    uint32_t xform;    // index of the OUTERMOST level of the chain in xforms; the levels of one leaf are consecutive
+    uint32_t aux;      // MEDIUM: key of its free-flight draws (include/rt_rng.h)
 }; // 16 B
 struct alignas(16) RtPrimGeo {
     double g[4];

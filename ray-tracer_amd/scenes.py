@@ -72,6 +72,8 @@ class SceneDesc:
     textures: list = field(default_factory=list)    # ("solid", (r,g,b)) | ("checker", a, b) | ("image", ndarray HxWx3 u8)
     materials: list = field(default_factory=list)   # ("lambertian", tex) | ("metal", tex, fuzz) | ("dielectric", ior) | ("diffuse_light", tex) | ("isotropic", tex)
     geometries: list = field(default_factory=list)  # ("sphere", r) | ("rectangle", w, h) | ("cube", w, h, d) | ("medium", geom, density)
+                                                    # | ("transformed", geom, M16) | ("bvh", [sprite ids]): a node used as a geometry
+                                                    #   (instancing); its sprites must precede the sprite that carries it
     sprites: list = field(default_factory=list)     # (geom | None, mat | None, M16 list | None)
     world: list | None = None                       # nesting of sprite ids as the reference nests BVH nodes; None = all sprites flat
     camera: tuple = ()                              # (eye, center, up, fov, aspect, focus, lens)
@@ -275,13 +277,31 @@ def build_product(desc: SceneDesc, device: int = 0):
             raise ValueError(t[0])
     for m in desc.materials:
         getattr(sc, m[0])(*m[1:])
-    for gm in desc.geometries:
-        if gm[0] == "medium":
-            sc.constant_medium(gm[1], gm[2])
-        else:
-            getattr(sc, gm[0])(*gm[1:])
+    # geometries are created on demand so that a node geometry ("bvh") finds its sprites already recorded; sprites are
+    # recorded strictly in description order (their indices key the random draws of instanced media, include/rt_rng.h)
+    gid = {}
+
+    def geometry(i):
+        if i is None:
+            return None
+        if i not in gid:
+            gm = desc.geometries[i]
+            if gm[0] == "medium":
+                gid[i] = sc.constant_medium(geometry(gm[1]), gm[2])
+            elif gm[0] == "transformed":
+                gid[i] = sc.transformed(geometry(gm[1]), gm[2])
+            elif gm[0] == "bvh":
+                assert all(c < n_done[0] for c in gm[1]), "a node's sprites must be described before the sprite that carries the node"
+                gid[i] = sc.bvh(gm[1])
+            else:
+                gid[i] = getattr(sc, gm[0])(*gm[1:])
+        return gid[i]
+
+    n_done = [0]
     for (gi, mi, M) in desc.sprites:
-        sc.sprite(gi, mi, M)
+        got = sc.sprite(geometry(gi), mi, M)
+        assert got == n_done[0]
+        n_done[0] += 1
     sc.commit(device)
     cam = rt.Camera(*desc.camera)
     return sc, cam

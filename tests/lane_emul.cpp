@@ -23,7 +23,7 @@ struct ArrayStack {
 
 // One lane's state machine run to completion: the wave-vote loop of render_kernel only
 // decides WHEN a lane's next step runs, never what it computes.
-template <bool G, bool M, bool T, bool LENS>
+template <bool G, int M, bool T, bool LENS>
 void run(const RtLaunch &L, int x0, int y0, int x1, int y1, double *out, double *samples_out, int sx, int sy,
          unsigned long long *cnt, int *stack_high) {
     ArrayStack st;
@@ -108,14 +108,14 @@ extern "C" int lane_emul_render(rt_scene *s, const rt_camera *cam, int W, int H,
             }
     } else if (!general) {
         if (lens)
-            run<false, false, false, true>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
+            run<false, 0, false, true>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
         else
-            run<false, false, false, false>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
+            run<false, 0, false, false>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
     } else {
         if (lens)
-            run<true, true, true, true>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
+            run<true, 2, true, true>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
         else
-            run<true, true, true, false>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
+            run<true, 2, true, false>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
     }
     if (counters) std::memcpy(counters, cnt, sizeof cnt);
     if (stack_high) *stack_high = hw;

@@ -46,9 +46,21 @@ def test_error_conventions(rt):
     with pytest.raises(rt.RtError):
         s.sprite(5, None)  # unknown geometry
     r = s.rectangle(1, 1)
+    m = s.constant_medium(r, 0.1)  # ConstantMedium<T: Hit>: any boundary (src/volume.rs:40-43) ...
     with pytest.raises(rt.RtError) as e:
-        s.constant_medium(r, 0.1)
+        s.constant_medium(m, 0.1)  # ... but a medium
     assert e.value.code == -4
+    with pytest.raises(rt.RtError) as e:
+        s.bvh([])  # BoundingVolumeHierarchyNode::new(vec![]) -> None
+    assert e.value.code == -2
+    with pytest.raises(rt.RtError):
+        s.bvh([7])  # unknown sprite
+    child = s.sprite(s.sphere(0.5), None)
+    node = s.bvh([child])
+    with pytest.raises(rt.RtError) as e:
+        s.bvh([child])  # already moved into a node
+    assert e.value.code == -5
+    s.sprite(node, None)
     g = s.sphere(1.0)
     s.sprite(g, None)
     s.commit(-1)
@@ -159,12 +171,15 @@ def test_flatten_book_one(rt, scenes):
 def test_flatten_cornell_and_cover(rt, scenes):
     sc, _ = scenes.build_product(scenes.cornell(), device=-1)
     info = _check_bvh(sc)
-    assert info["n_prims"] == 8 and info["n_child_prims"] == 12  # two cubes x six faces
+    # 6 rectangles + two cubes expanded into six rectangle leaves each (chain = sprite matrix, face matrix); the walls
+    # span the scene but their boxes are flat: nothing is hoisted
+    assert info["n_prims"] == 6 + 12 and info["n_child_prims"] == 0 and info["n_hoisted"] == 0
+    assert info["n_xforms"] == 6 + 12 * 2
     assert info["feature_mask"] & rt.RT_FEAT_GENERAL
     d = scenes.cover(1)
     sc, _ = scenes.build_product(d, device=-1)
     info = _check_bvh(sc)
-    assert info["n_prims"] == 400 + 1 + 4 + 1 + 1 + 1 + 1000 and info["n_child_prims"] == 2400
+    assert info["n_prims"] == 2400 + 1 + 4 + 1 + 1 + 1 + 1000 and info["n_child_prims"] == 0
     assert info["feature_mask"] & rt.RT_FEAT_MEDIUM and info["feature_mask"] & rt.RT_FEAT_TEXTURED
     assert 1 <= info["n_hoisted"] <= 4  # the r = 5000 fog at least
 
