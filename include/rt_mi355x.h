@@ -202,7 +202,7 @@ int rt_last_kernel_ms(rt_scene *, float *ms);
  * dispatch are not reliable for these kernels): persistent workgroups, threads per workgroup, dynamic LDS per
  * workgroup, resident workgroups per CU, CUs, passes over the sample workspace, jobs of the last pass and their size,
  * kernel family feature bits (1 general prims, 2 media, 4 textures), whether the node array is in LDS and the
- * swap-at-shade queues are in use, and the bytes of per-sample workspace the render used */
+ * swap-at-shade queues are in use (and their capacity), and the bytes of per-sample workspace the render used */
 typedef struct rt_launch_config {
     int blocks, block_threads;
     unsigned lds_bytes;
@@ -211,6 +211,7 @@ typedef struct rt_launch_config {
     unsigned kernel_features;
     int lds_nodes, swap;
     size_t workspace_bytes;
+    int swap_cap, waves_per_simd; /* entries per swap queue; waves per SIMD the kernel family is compiled for */
 } rt_launch_config;
 int rt_last_launch_config(rt_scene *, rt_launch_config *out);
 

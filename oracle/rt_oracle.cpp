@@ -192,6 +192,8 @@ struct Ctx {
     rt_rng rng;
     uint32_t segment = 0;     // index of the current path segment (keyed medium draws)
     uint32_t medium_slot = 0; // slot of the sprite whose geometry is being tested
+    uint64_t path_hash = 0;   // creation indices of the sprites entered so far, folded (include/rt_rng.h, rt_medium_key_nested)
+    int path_len = 0;         // sprites entered so far: 1 = a sprite of the world's own list
     orc_counters cnt{0, 0, 0, 0, 0};
     double next53() { // rand::random::<f64>()
         ++cnt.rng_draws;
@@ -207,7 +209,9 @@ struct Ctx {
     }
     double keyed01() { // ConstantMedium's gen_range(0.0, 1.0): see rt_rng.h
         ++cnt.rng_draws;
-        return rt_u64_to_range01(rt_rng_keyed_from_base(rng.base, segment, medium_slot));
+        // a medium inside instanced geometry (more than one sprite above it) is keyed by its path: every instance its own draws
+        const uint32_t key = path_len > 1 ? rt_medium_key_nested(path_hash) : medium_slot;
+        return rt_u64_to_range01(rt_rng_keyed_from_base(rng.base, segment, key));
     }
 };
 
@@ -317,6 +321,7 @@ struct Scene {
     std::unique_ptr<Object> world;
     int world_nodes = 0;
     int medium_slots = 0;
+    uint64_t n_sprites = 0;
     double hyp_param = 0.0;
     unsigned hypothesis = 0; // ORC_HYP_*: earlier forms of the reference's code the cover.png probes try (never a default)
     // camera (camera.rs:10-21)
@@ -593,13 +598,19 @@ struct Sprite : Object { // sprite.rs:11-139
     int geometry, material; // Option<Arc<T>>, Option<Arc<U>>
     Mat4Cached transform;
     uint32_t medium_slot = 0x3FFu;
+    uint64_t sid = 0; // creation index among the sprites
     Sprite(int g, int m, const Mat4 &t) : geometry(g), material(m), transform(t) {}
     bool hit(const Scene &s, Ctx &c, const Ray &ray, HitRecord *rec) const override { // sprite.rs:94-138
         if (geometry < 0) return false;
-        uint32_t saved = c.medium_slot;
+        const uint32_t saved = c.medium_slot;
+        const uint64_t saved_hash = c.path_hash;
         c.medium_slot = medium_slot;
+        c.path_hash = c.path_len == 0 ? sid + 1ull : c.path_hash * RT_RNG_PATH_MUL + sid + 1ull;
+        ++c.path_len;
         bool ok = transformed_hit(transform, ray, rec,
                                   [&](const Ray &r, HitRecord *lr) { return s.geometries[geometry]->hit(s, c, r, lr); });
+        --c.path_len;
+        c.path_hash = saved_hash;
         c.medium_slot = saved;
         if (ok) rec->material = material;
         return ok;
@@ -930,6 +941,7 @@ int orc_sprite(orc_scene *p, int geometry, int material, const double *M) {
     Mat4 m = mat4_identity();
     if (M) std::memcpy(m.a, M, sizeof m.a);
     Sprite *sp = new Sprite(geometry, material, m);
+    sp->sid = p->s.n_sprites++;
     if (geometry >= 0 && dynamic_cast<ConstantMedium *>(p->s.geometries[geometry].get())) {
         sp->medium_slot = (uint32_t)(p->s.medium_slots++) & 0x3FFu;
     }
@@ -940,6 +952,20 @@ static std::vector<const Object *> gather(orc_scene *p, const int *objects, int 
     std::vector<const Object *> v;
     for (int i = 0; i < n; ++i) v.push_back(p->s.objects[objects[i]].get());
     return v;
+}
+int orc_geom_bvh(orc_scene *p, const int *objects, int n, uint64_t seed) {
+    rt_rng g;
+    rt_rng_init(&g, seed, RT_RNG_SCENE_STREAM);
+    auto node = BVHNode::make(p->s, gather(p, objects, n), &g);
+    if (!node) return -1;
+    p->s.geometries.push_back(std::move(node));
+    return (int)p->s.geometries.size() - 1;
+}
+int orc_geom_transformed(orc_scene *p, int geometry, const double *M) {
+    Mat4 m = mat4_identity();
+    if (M) std::memcpy(m.a, M, sizeof m.a);
+    p->s.geometries.emplace_back(new TransformedGeometry(std::unique_ptr<Object>(new GeometryRef(geometry)), m));
+    return (int)p->s.geometries.size() - 1;
 }
 int orc_object_bvh(orc_scene *p, const int *objects, int n, uint64_t seed) {
     rt_rng g;

@@ -69,6 +69,11 @@ int orc_geom_sphere(orc_scene *, double radius);
 int orc_geom_rectangle(orc_scene *, double w, double h);
 int orc_geom_cube_bvh(orc_scene *, double w, double h, double d, uint64_t bvh_seed);
 int orc_geom_constant_medium(orc_scene *, int boundary_geom, double density);
+/* BoundingVolumeHierarchyNode::new(objects) used as a sprite's GEOMETRY: instancing (src/sprite.rs:87-93 with
+ * T = BoundingVolumeHierarchyNode, examples/cornell-box.rs:85-101); TransformedGeometry::new(geometry, M)
+ * (src/geometry.rs:185-246) */
+int orc_geom_bvh(orc_scene *, const int *objects, int n, uint64_t bvh_seed);
+int orc_geom_transformed(orc_scene *, int geometry, const double *M);
 
 /* Sprite::builder().geometry().material().transform().build() (src/sprite.rs:22-72)
  * -> object id.  geometry / material = -1 for None; M = 16 doubles column-major

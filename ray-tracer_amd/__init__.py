@@ -26,7 +26,7 @@ LIB_PATH = Path(os.environ.get("RT_MI355X_LIB") or (_HERE / "lib" / "librt_mi355
 
 RT_TILE = 8
 RT_FLAG_COUNTERS = 1
-RT_FEAT_SPHERE_T, RT_FEAT_GENERAL, RT_FEAT_MEDIUM, RT_FEAT_TEXTURED, RT_FEAT_LENS = 1, 2, 4, 8, 16
+RT_FEAT_SPHERE_T, RT_FEAT_GENERAL, RT_FEAT_MEDIUM, RT_FEAT_TEXTURED, RT_FEAT_LENS, RT_FEAT_MEDIUM_GENERAL = 1, 2, 4, 8, 16, 32
 
 
 class RtError(RuntimeError):
@@ -70,7 +70,8 @@ class rt_scene_info(C.Structure):
 class rt_launch_config(C.Structure):
     _fields_ = [("blocks", C.c_int), ("block_threads", C.c_int), ("lds_bytes", C.c_uint), ("blocks_per_cu", C.c_int),
                 ("n_cu", C.c_int), ("passes", C.c_int), ("n_jobs", C.c_int), ("job_spp", C.c_int),
-                ("kernel_features", C.c_uint), ("lds_nodes", C.c_int), ("swap", C.c_int), ("workspace_bytes", C.c_size_t)]
+                ("kernel_features", C.c_uint), ("lds_nodes", C.c_int), ("swap", C.c_int), ("workspace_bytes", C.c_size_t),
+                ("swap_cap", C.c_int), ("waves_per_simd", C.c_int)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -26,7 +26,8 @@ extern "C" int rt_launch_reduce(const double *samples, double *tiles, int n_owne
                                 int spp, int width, int height, int shard_index, int shard_count, void *stream);
 extern "C" int rt_kernel_block_size(unsigned features);
 extern "C" int rt_kernel_waves_per_simd(unsigned features);
-extern "C" unsigned rt_swap_lds_bytes(void);
+extern "C" unsigned rt_swap_lds_bytes(unsigned cap);
+extern "C" unsigned rt_swap_cap_max(void);
 extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int ldsnodes, unsigned lds_bytes, int *blocks_per_cu,
                                     int *n_cu);
 extern "C" int rt_launch_unpack(const double *gathered, int tiles_per_shard, int shard_count, int width, int height,
@@ -380,11 +381,22 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     // swap-at-shade queues (rt_kernels.hip); RT_SWAP=0 selects the kernels without them (A/B runs)
     const char *swap_env = std::getenv("RT_SWAP");
     const int swap = !(swap_env && *swap_env == '0');
-    const unsigned swap_bytes = swap ? rt_swap_lds_bytes() : 0u;
-    // keep the kernel family's full occupancy resident: that many workgroups per CU, each with its own node copy
+    // keep the kernel family's full occupancy resident: that many workgroups per CU, each with its own stack, node
+    // copy (when it fits) and swap queues (as many entries as fit, 16 at least)
     const unsigned groups_per_cu = std::max(1u, (unsigned)rt_kernel_waves_per_simd(feat) * 256u / block);
-    const int ldsnodes = node_bytes > 0 && groups_per_cu * (stack_bytes + node_bytes + swap_bytes) <= 160u * 1024u &&
+    const unsigned lds_share = (160u * 1024u / groups_per_cu) & ~511u; // LDS is handed out in 512-byte granules
+    auto swap_cap_that_fits = [&](unsigned other) -> unsigned {
+        if (!swap) return 0u;
+        const unsigned per_entry = rt_swap_lds_bytes(2) - rt_swap_lds_bytes(1), hdr = rt_swap_lds_bytes(1) - per_entry;
+        if (block >= 512u) return rt_swap_cap_max(); // compiled in for the 512-thread families
+        if (other + hdr + 16u * per_entry > lds_share) return 16u; // does not fit anyway: fewer groups will be resident
+        return std::min(rt_swap_cap_max(), (lds_share - other - hdr) / per_entry);
+    };
+    const int ldsnodes = node_bytes > 0 && stack_bytes + node_bytes + (swap ? rt_swap_lds_bytes(block >= 512u ? 0u : 32u) : 0u) <= lds_share &&
                          !(no_lds && *no_lds == '1');
+    const unsigned swap_cap = swap_cap_that_fits(stack_bytes + (ldsnodes ? node_bytes : 0u));
+    const unsigned swap_bytes = swap ? rt_swap_lds_bytes(swap_cap) : 0u;
+    L.swap_cap = (int)swap_cap;
     const unsigned lds_bytes = stack_bytes + (ldsnodes ? node_bytes : 0u) + swap_bytes;
     const int lds_mode = (ldsnodes ? 1 : 0) | (swap ? 2 : 0);
     int per_cu = 0, n_cu = 0, rc = 0;
@@ -458,6 +470,8 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     lc.lds_nodes = ldsnodes;
     lc.swap = swap;
     lc.workspace_bytes = need;
+    lc.swap_cap = (int)swap_cap;
+    lc.waves_per_simd = rt_kernel_waves_per_simd(feat);
     return RT_OK;
 }
 

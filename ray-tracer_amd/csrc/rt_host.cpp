@@ -534,6 +534,9 @@ struct Flattener {
             lf.meta.aux = path_len == 1 ? top_slot : rt_medium_key_nested(path_hash);
             const GeometryIR &b = ir.geometries[(size_t)g.boundary];
             fs.feature_mask |= RT_FEAT_MEDIUM;
+            // a medium whose material reads uv (src/volume.rs:64-66: the sums over both boundary hits) goes to the kernel
+            // family that keeps uv inside the medium test
+            if (material != RT_NO_MATERIAL && !fs.materials[material].solid) fs.feature_mask |= RT_FEAT_MEDIUM_GENERAL;
             if (b.kind == GEO_SPHERE && chain.size() == 1 && chain[0].translation) {
                 lf.meta.kind = RT_PRIM_MEDIUM_T; // examples/main.rs:241-263
                 lf.geo.g[0] = chain[0].M[12];
@@ -623,11 +626,12 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
     Flattener fl{ir, fs};
     for (size_t si = 0; si < ir.sprites.size(); ++si) {
         const SpriteIR &s = ir.sprites[si];
+        // slots count the medium sprites in creation order, wherever they end up; a sprite that reaches a medium only
+        // through a TransformedGeometry has none (0x3FF)
+        uint32_t slot = 0x3FFu;
+        if (s.geometry >= 0 && ir.geometries[(size_t)s.geometry].kind == GEO_MEDIUM) slot = (fl.medium_slots++) & 0x3FFu;
         if (s.owned) continue;        // moved into a BoundingVolumeHierarchyNode geometry
         if (s.geometry < 0) continue; // geometry None: never hit (src/sprite.rs:95,136)
-        const GeometryIR &g = ir.geometries[(size_t)s.geometry];
-        uint32_t slot = 0;
-        if (g.kind == GEO_MEDIUM) slot = (fl.medium_slots++) & 0x3FFu; // slots count the world's medium sprites in creation order
         Link l;
         if (!make_link(s.M, &l)) continue; // det == 0: unhittable (src/sprite.rs:131-134)
         const uint32_t material = s.material < 0 ? RT_NO_MATERIAL : (uint32_t)s.material;

@@ -45,7 +45,10 @@
 #define RT_BLOCK 512 /* threads per workgroup: 8 waves share one LDS copy of the node array */
 #endif
 #ifndef RT_BLOCK_GENERAL
-#define RT_BLOCK_GENERAL 512 /* general kernel with media / textures: 245 VGPRs, 2 waves per SIMD = one workgroup per CU */
+#define RT_BLOCK_GENERAL 512 /* kernel with media over general boundaries: 256 VGPRs, 2 waves per SIMD = one workgroup per CU */
+#endif
+#ifndef RT_BLOCK_MEDIUM
+#define RT_BLOCK_MEDIUM 256 /* general prims + sphere media + textures (the book-two cover): 3 waves per SIMD as three groups per CU */
 #endif
 // the general kernel without medium / texture code (Cornell box) needs 157 VGPRs = 3 waves per SIMD: three workgroups
 // of 4 waves (one per SIMD) per CU.  6-wave groups (384 threads) do NOT work: the second group no longer fits the
@@ -79,10 +82,13 @@
 #define RT_WAVES_PER_EU 4 /* spheres-only kernel: 105 VGPRs fit 4 waves per SIMD */
 #endif
 #ifndef RT_WAVES_PER_EU_LEAN
-#define RT_WAVES_PER_EU_LEAN 3 /* general prims without media / textures: 157 VGPRs */
+#define RT_WAVES_PER_EU_LEAN 4 /* general prims without media / textures: 128 VGPRs, four 256-thread groups per CU (+15 % on the Cornell box over 3) */
 #endif
 #ifndef RT_WAVES_PER_EU_GENERAL
-#define RT_WAVES_PER_EU_GENERAL 2 /* general kernel (matrices, cubes, media, textures) needs the registers */
+#define RT_WAVES_PER_EU_GENERAL 2 /* media over general boundaries (medium_general_hit) need the registers */
+#endif
+#ifndef RT_WAVES_PER_EU_MEDIUM
+#define RT_WAVES_PER_EU_MEDIUM 4
 #endif
 
 // iterations of the unit-ball rejection sampler per shade block (0 = run it to the end, like the reference's loop);
@@ -97,7 +103,7 @@
 // bulk the same way ("new" mode).  Nothing ever waits: a busy queue lock or a full queue just means the lane is
 // shaded in place.  Which lane or wave finishes a path cannot change its result (per-sample streams and records).
 #ifndef RT_SWAP_CAP
-#define RT_SWAP_CAP 64 /* entries per class queue */
+#define RT_SWAP_CAP 64 /* entries per class queue at most; fewer when four 256-thread groups have to share a CU's LDS */
 #endif
 #ifndef RT_SWAP_MODE_MIN
 #define RT_SWAP_MODE_MIN 56 /* a class needs this many lanes (own + parked) to be chosen over starting new samples */
@@ -124,8 +130,7 @@
 #define RT_SWAP_F64 14     /* o, d, T (9), s0, s1, best_t, draws, base */
 #define RT_SWAP_F32 3      /* k, best_prim, slot */
 #define RT_SWAP_HDR_BYTES 32u
-#define RT_SWAP_CLASS_BYTES ((unsigned)((RT_SWAP_F64 * 8 + RT_SWAP_F32 * 4) * RT_SWAP_CAP))
-#define RT_SWAP_LDS_BYTES (RT_SWAP_HDR_BYTES + RT_SWAP_CLASSES * RT_SWAP_CLASS_BYTES)
+#define RT_SWAP_ENTRY_BYTES ((unsigned)(RT_SWAP_F64 * 8 + RT_SWAP_F32 * 4))
 
 namespace {
 
@@ -143,10 +148,10 @@ struct LdsStack {
 };
 // workgroup size and waves per SIMD of each kernel family
 __host__ __device__ constexpr int block_of(bool general, int medium) {
-    return general ? (medium ? RT_BLOCK_GENERAL : RT_BLOCK_LEAN) : RT_BLOCK;
+    return general ? (medium >= 2 ? RT_BLOCK_GENERAL : (medium == 1 ? RT_BLOCK_MEDIUM : RT_BLOCK_LEAN)) : RT_BLOCK;
 }
 __host__ __device__ constexpr int waves_of(bool general, int medium) {
-    return general ? (medium ? RT_WAVES_PER_EU_GENERAL : RT_WAVES_PER_EU_LEAN) : RT_WAVES_PER_EU;
+    return general ? (medium >= 2 ? RT_WAVES_PER_EU_GENERAL : (medium == 1 ? RT_WAVES_PER_EU_MEDIUM : RT_WAVES_PER_EU_LEAN)) : RT_WAVES_PER_EU;
 }
 
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) { // set bits below this lane
@@ -162,6 +167,10 @@ extern __shared__ __attribute__((aligned(16))) unsigned char rt_lds[];
 template <bool GENERAL, int MEDIUM, bool TEXTURED, bool LENS, bool COUNT, bool LDSNODES, bool SWAP>
 __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM)) void render_kernel(const RtLaunch L) {
     constexpr int kBlock = block_of(GENERAL, MEDIUM);
+    // entries per class queue: the most (<= RT_SWAP_CAP) that leaves the kernel family's full occupancy resident (host)
+    // (a compile-time constant for the 512-thread families: the address arithmetic of a run-time capacity costs the
+    // book-one kernel 2 %)
+    const uint32_t kSwapCap = kBlock >= 512 ? (uint32_t)RT_SWAP_CAP : (uint32_t)L.swap_cap, kSwapClassBytes = RT_SWAP_ENTRY_BYTES * kSwapCap;
     uint32_t *stack_mem = reinterpret_cast<uint32_t *>(rt_lds);
     LdsStack<kBlock> st;
     st.base = stack_mem + threadIdx.x;
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                 if (lane < (uint32_t)RT_SWAP_CLASSES) {
                     my_n = lane == 0u ? n0 : (lane == 1u ? n1 : n2);
                     const uint32_t my_q = lane == 0u ? q0 : (lane == 1u ? q1 : q2);
-                    const bool push_c = allow_push && (mode_new || lane != cstar) && my_n > 0u && my_q < (uint32_t)RT_SWAP_CAP;
+                    const bool push_c = allow_push && (mode_new || lane != cstar) && my_n > 0u && my_q < kSwapCap;
                     const bool pull_c = !mode_new && lane == cstar && my_q > 0u;
                     if (push_c || pull_c) {
                         // One compare-and-swap both takes the lock and learns the exact count: count -> count | lock.
@@ -341,26 +350,26 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                     const unsigned long long mc = cls == 0u ? m0 : (cls == 1u ? m1 : m2);
                     const uint32_t g = cls == 0u ? g0 : (cls == 1u ? g1 : g2), c = cls == 0u ? k0 : (cls == 1u ? k1 : k2);
                     const uint32_t idx = c + lane_rank(mc);
-                    if (g != 0u && idx < (uint32_t)RT_SWAP_CAP) {
-                        double *f64 = reinterpret_cast<double *>(qbase + cls * RT_SWAP_CLASS_BYTES) + idx;
-                        uint32_t *f32 = reinterpret_cast<uint32_t *>(qbase + cls * RT_SWAP_CLASS_BYTES + RT_SWAP_F64 * 8 * RT_SWAP_CAP) + idx;
-                        f64[0 * RT_SWAP_CAP] = ps.o.x;
-                        f64[1 * RT_SWAP_CAP] = ps.o.y;
-                        f64[2 * RT_SWAP_CAP] = ps.o.z;
-                        f64[3 * RT_SWAP_CAP] = ps.d.x;
-                        f64[4 * RT_SWAP_CAP] = ps.d.y;
-                        f64[5 * RT_SWAP_CAP] = ps.d.z;
-                        f64[6 * RT_SWAP_CAP] = ps.T.x;
-                        f64[7 * RT_SWAP_CAP] = ps.T.y;
-                        f64[8 * RT_SWAP_CAP] = ps.T.z;
-                        f64[9 * RT_SWAP_CAP] = __longlong_as_double((long long)ps.g.s0);
-                        f64[10 * RT_SWAP_CAP] = __longlong_as_double((long long)ps.g.s1);
-                        f64[11 * RT_SWAP_CAP] = tv.best_t;
-                        if (COUNT) f64[12 * RT_SWAP_CAP] = __longlong_as_double((long long)ps.g.draws);
-                        if (MEDIUM) f64[13 * RT_SWAP_CAP] = __longlong_as_double((long long)ps.g.base);
-                        f32[0 * RT_SWAP_CAP] = (uint32_t)ps.k;
-                        f32[1 * RT_SWAP_CAP] = tv.best_prim;
-                        f32[2 * RT_SWAP_CAP] = slot;
+                    if (g != 0u && idx < kSwapCap) {
+                        double *f64 = reinterpret_cast<double *>(qbase + cls * kSwapClassBytes) + idx;
+                        uint32_t *f32 = reinterpret_cast<uint32_t *>(qbase + cls * kSwapClassBytes + RT_SWAP_F64 * 8 * kSwapCap) + idx;
+                        f64[0 * kSwapCap] = ps.o.x;
+                        f64[1 * kSwapCap] = ps.o.y;
+                        f64[2 * kSwapCap] = ps.o.z;
+                        f64[3 * kSwapCap] = ps.d.x;
+                        f64[4 * kSwapCap] = ps.d.y;
+                        f64[5 * kSwapCap] = ps.d.z;
+                        f64[6 * kSwapCap] = ps.T.x;
+                        f64[7 * kSwapCap] = ps.T.y;
+                        f64[8 * kSwapCap] = ps.T.z;
+                        f64[9 * kSwapCap] = __longlong_as_double((long long)ps.g.s0);
+                        f64[10 * kSwapCap] = __longlong_as_double((long long)ps.g.s1);
+                        f64[11 * kSwapCap] = tv.best_t;
+                        if (COUNT) f64[12 * kSwapCap] = __longlong_as_double((long long)ps.g.draws);
+                        if (MEDIUM) f64[13 * kSwapCap] = __longlong_as_double((long long)ps.g.base);
+                        f32[0 * kSwapCap] = (uint32_t)ps.k;
+                        f32[1 * kSwapCap] = tv.best_prim;
+                        f32[2 * kSwapCap] = slot;
                         has_path = false;
                         cls = kEmpty;
                         if (COUNT) ++w_park;
@@ -369,7 +378,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                 // the parked classes are done: publish their counts and free their locks before the pull (shorter hold time)
                 bool released = false;
                 if (RT_SWAP_EARLY_RELEASE && got != 0u && (mode_new || lane != cstar)) {
-                    __hip_atomic_store(&swap_hdr[lane], cnt + min(my_n, (uint32_t)RT_SWAP_CAP - cnt), __ATOMIC_RELEASE,
+                    __hip_atomic_store(&swap_hdr[lane], cnt + min(my_n, kSwapCap - cnt), __ATOMIC_RELEASE,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
                     released = true;
                 }
@@ -384,20 +393,20 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                         const uint32_t r = lane_rank(mF);
                         if (cls == kEmpty && r < pulled) {
                             const uint32_t idx = avail - 1u - r;
-                            const double *f64 = reinterpret_cast<const double *>(qbase + cstar * RT_SWAP_CLASS_BYTES) + idx;
+                            const double *f64 = reinterpret_cast<const double *>(qbase + cstar * kSwapClassBytes) + idx;
                             const uint32_t *f32 =
-                                reinterpret_cast<const uint32_t *>(qbase + cstar * RT_SWAP_CLASS_BYTES + RT_SWAP_F64 * 8 * RT_SWAP_CAP) + idx;
-                            ps.o = rtl::mk(f64[0 * RT_SWAP_CAP], f64[1 * RT_SWAP_CAP], f64[2 * RT_SWAP_CAP]);
-                            ps.d = rtl::mk(f64[3 * RT_SWAP_CAP], f64[4 * RT_SWAP_CAP], f64[5 * RT_SWAP_CAP]);
-                            ps.T = rtl::mk(f64[6 * RT_SWAP_CAP], f64[7 * RT_SWAP_CAP], f64[8 * RT_SWAP_CAP]);
-                            ps.g.s0 = (uint64_t)__double_as_longlong(f64[9 * RT_SWAP_CAP]);
-                            ps.g.s1 = (uint64_t)__double_as_longlong(f64[10 * RT_SWAP_CAP]);
-                            tv.best_t = f64[11 * RT_SWAP_CAP];
-                            if (COUNT) ps.g.draws = (unsigned long long)__double_as_longlong(f64[12 * RT_SWAP_CAP]);
-                            if (MEDIUM) ps.g.base = (uint64_t)__double_as_longlong(f64[13 * RT_SWAP_CAP]);
-                            ps.k = (int32_t)f32[0 * RT_SWAP_CAP];
-                            tv.best_prim = f32[1 * RT_SWAP_CAP];
-                            slot = f32[2 * RT_SWAP_CAP];
+                                reinterpret_cast<const uint32_t *>(qbase + cstar * kSwapClassBytes + RT_SWAP_F64 * 8 * kSwapCap) + idx;
+                            ps.o = rtl::mk(f64[0 * kSwapCap], f64[1 * kSwapCap], f64[2 * kSwapCap]);
+                            ps.d = rtl::mk(f64[3 * kSwapCap], f64[4 * kSwapCap], f64[5 * kSwapCap]);
+                            ps.T = rtl::mk(f64[6 * kSwapCap], f64[7 * kSwapCap], f64[8 * kSwapCap]);
+                            ps.g.s0 = (uint64_t)__double_as_longlong(f64[9 * kSwapCap]);
+                            ps.g.s1 = (uint64_t)__double_as_longlong(f64[10 * kSwapCap]);
+                            tv.best_t = f64[11 * kSwapCap];
+                            if (COUNT) ps.g.draws = (unsigned long long)__double_as_longlong(f64[12 * kSwapCap]);
+                            if (MEDIUM) ps.g.base = (uint64_t)__double_as_longlong(f64[13 * kSwapCap]);
+                            ps.k = (int32_t)f32[0 * kSwapCap];
+                            tv.best_prim = f32[1 * kSwapCap];
+                            slot = f32[2 * kSwapCap];
                             tv.cur = RT_CUR_DONE;
                             tv.sp = 0;
                             has_path = true;
@@ -413,7 +422,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                     if (!mode_new && lane == cstar)
                         now = cnt - pulled;
                     else
-                        now = cnt + min(my_n, (uint32_t)RT_SWAP_CAP - cnt);
+                        now = cnt + min(my_n, kSwapCap - cnt);
                     __hip_atomic_store(&swap_hdr[lane], now, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); // count without the lock bit
                 }
                 if (COUNT && RT_SWAP_PROBE == 6) // cycles of classification + queue traffic (steps 1-6), part of finish_cycles
@@ -700,12 +709,19 @@ extern "C" int rt_launch_render(const RtLaunch *L, unsigned features, int lens, 
 }
 
 // threads per workgroup of the kernel family that serves these feature bits (see pick())
-extern "C" int rt_kernel_block_size(unsigned features) { return features == 0u ? RT_BLOCK : (features == 1u ? RT_BLOCK_LEAN : RT_BLOCK_GENERAL); }
+extern "C" int rt_kernel_block_size(unsigned features) {
+    return features == 0u ? RT_BLOCK : (features == 1u ? RT_BLOCK_LEAN : ((features & 8u) ? RT_BLOCK_GENERAL : RT_BLOCK_MEDIUM));
+}
 // waves per SIMD that family is compiled for: (that x 4 SIMDs x 64) / block size workgroups share a CU's LDS
 extern "C" int rt_kernel_waves_per_simd(unsigned features) {
-    return features == 0u ? RT_WAVES_PER_EU : (features == 1u ? RT_WAVES_PER_EU_LEAN : RT_WAVES_PER_EU_GENERAL);
+    return features == 0u ? RT_WAVES_PER_EU
+                          : (features == 1u ? RT_WAVES_PER_EU_LEAN : ((features & 8u) ? RT_WAVES_PER_EU_GENERAL : RT_WAVES_PER_EU_MEDIUM));
 }
-extern "C" unsigned rt_swap_lds_bytes(void) { return RT_SWAP_LDS_BYTES; }
+// dynamic LDS of the swap queues with `cap` entries per class; cap = 0 asks for the largest capacity
+extern "C" unsigned rt_swap_lds_bytes(unsigned cap) {
+    return RT_SWAP_HDR_BYTES + RT_SWAP_CLASSES * RT_SWAP_ENTRY_BYTES * (cap ? cap : (unsigned)RT_SWAP_CAP);
+}
+extern "C" unsigned rt_swap_cap_max(void) { return RT_SWAP_CAP; }
 
 // occupancy-derived size of the persistent grid
 extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int ldsnodes, unsigned lds_bytes, int *blocks_per_cu,

@@ -169,9 +169,33 @@ RT_HD bool sphere_t(V3 oc, V3 d, double a, double radius, double *t_out) {
     *t_out = t;
     return true;
 }
-RT_HD void sphere_uv(V3 q, double *u, double *v) { // unitSphereUv, src/geometry.rs:35-39
-    *u = 0.5 + atan2(q.x, q.z) / (2.0 * RTL_PI);
-    *v = 1.0 - acos(q.y) / RTL_PI;
+// ---- out-of-line transcendental helpers ----
+// atan2 / acos / sin / log expand to binary64 polynomials with a dozen 64-bit constants each.  Inlined into the
+// persistent kernel loop, the compiler hoists every one of those constants out of the loop and keeps them in registers for
+// the kernel's whole life (+70 VGPRs: 222 instead of 153, the difference between 2 and 3 waves per SIMD).  As real
+// functions they cost a call on paths that are rare (textured hits) or already expensive (a medium test).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_COLD __device__ __attribute__((noinline))
+#else
+#define RT_COLD static inline
+#endif
+struct UV {
+    double u, v;
+};
+RT_COLD UV sphere_uv_cold(double qx, double qy, double qz) { // unitSphereUv, src/geometry.rs:35-39
+    UV r;
+    r.u = 0.5 + atan2(qx, qz) / (2.0 * RTL_PI);
+    r.v = 1.0 - acos(qy) / RTL_PI;
+    return r;
+}
+RT_COLD double log_cold(double x) { return log(x); }
+RT_COLD double checker_sine_cold(double u, double v) { // src/material.rs:238
+    return sin(2.0 * RTL_PI * 10.0 * u) * sin(2.0 * RTL_PI * 10.0 * v);
+}
+RT_HD void sphere_uv(V3 q, double *u, double *v) {
+    const UV r = sphere_uv_cold(q.x, q.y, q.z);
+    *u = r.u;
+    *v = r.v;
 }
 // full local record for a known t (src/geometry.rs:66-71).  uv: the reference evaluates atan2 / acos on every hit; they
 // only ever reach Texture::value, so they are computed when the hit material's texture reads them (checker / image)
@@ -224,7 +248,7 @@ RT_HD bool medium_hit(V3 oc, V3 d, double radius, double density, uint64_t rng_b
         sphere_finish(o2, d, radius, t2, uv, &r2);
         double inside = r2.t;
         ++*draws;
-        double distance = (-1.0 / density) * log(rt_u64_to_range01(rt_rng_keyed_from_base(rng_base, segment, slot)));
+        double distance = (-1.0 / density) * log_cold(rt_u64_to_range01(rt_rng_keyed_from_base(rng_base, segment, slot)));
         if (distance > inside) return false;
         r->u = r1.u + r2.u;
         r->v = r1.v + r2.v;
@@ -235,7 +259,7 @@ RT_HD bool medium_hit(V3 oc, V3 d, double radius, double density, uint64_t rng_b
     }
     double inside = r1.t;
     ++*draws;
-    double distance = (-1.0 / density) * log(rt_u64_to_range01(rt_rng_keyed_from_base(rng_base, segment, slot)));
+    double distance = (-1.0 / density) * log_cold(rt_u64_to_range01(rt_rng_keyed_from_base(rng_base, segment, slot)));
     if (distance > inside) return false;
     r->u = r1.u;
     r->v = r1.v;
@@ -340,7 +364,7 @@ RT_HD bool medium_general_hit(const RtLaunch &L, const RtPrimGeo &G, V3 o, V3 d,
     if (dot(r1.n, d) < 0.0) {
         const double inside = r2.t;
         ++*draws;
-        const double distance = (-1.0 / density) * log(rt_u64_to_range01(rt_rng_keyed_from_base(rng_base, segment, slot)));
+        const double distance = (-1.0 / density) * log_cold(rt_u64_to_range01(rt_rng_keyed_from_base(rng_base, segment, slot)));
         if (distance > inside) return false;
         r->u = r1.u + r2.u;
         r->v = r1.v + r2.v;
@@ -351,7 +375,7 @@ RT_HD bool medium_general_hit(const RtLaunch &L, const RtPrimGeo &G, V3 o, V3 d,
     }
     const double inside = r1.t;
     ++*draws;
-    const double distance = (-1.0 / density) * log(rt_u64_to_range01(rt_rng_keyed_from_base(rng_base, segment, slot)));
+    const double distance = (-1.0 / density) * log_cold(rt_u64_to_range01(rt_rng_keyed_from_base(rng_base, segment, slot)));
     if (distance > inside) return false;
     r->u = r1.u;
     r->v = r1.v;
@@ -366,7 +390,9 @@ RT_HD bool medium_general_hit(const RtLaunch &L, const RtPrimGeo &G, V3 o, V3 d,
 // MEDIUM: 0 no media in the scene, 1 only ConstantMedium<Sphere> sprites under a pure translation (RT_PRIM_MEDIUM_T,
 // the reference's own scenes), 2 media over any boundary (RT_PRIM_MEDIUM_C) as well.
 template <bool GENERAL, int MEDIUM, bool RECORD>
-RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx &sc, Rec *r, bool uv) {
+RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx &sc, Rec *r, bool uv_wanted) {
+    // uv inside the record is only ever asked for by prim_uv's medium case (kernel family MEDIUM = 2)
+    const bool uv = MEDIUM >= 2 && uv_wanted;
     const RtPrimGeo &G = L.prim_geo[pi];
     uint32_t kw = (uint32_t)RT_PRIM_SPHERE_T;
     if (GENERAL || MEDIUM) kw = L.prim_meta[pi].kind; // bits 8-15 carry the material's kind, 16-23 the chain
@@ -583,7 +609,7 @@ RT_HD V3 texture_value(const RtLaunch &L, uint32_t tex, double u, double v) {
         const RtTexture &T = L.textures[tex];
         if (T.kind == RT_TEX_SOLID) return ld3(T.rgb);
         if (T.kind == RT_TEX_CHECKER) {
-            double sine = sin(2.0 * RTL_PI * 10.0 * u) * sin(2.0 * RTL_PI * 10.0 * v);
+            double sine = checker_sine_cold(u, v);
             tex = sine > 0.0 ? T.a : T.b;
             continue;
         }
@@ -618,12 +644,10 @@ RT_HD bool schlick_reflects(double c, double n1, double n2, double u) {
 // sampler and the final normalisation are shared, so a wave with mixed materials
 // executes each of them once.  Per lane the operations (and the random draws) are
 // exactly those of its own material's scatter().
-template <bool TEXTURED>
-RT_HD bool shade(const RtLaunch &L, const RtMaterial &M, const Rec &rec, V3 d_in, Rng &g, V3 *o_out, V3 *d_out, V3 *att,
-                 V3 *emit, int ball_iters = 0, bool *pending = nullptr) {
+// `tex` = the value of the material's texture at the hit (albedo / emission)
+RT_HD bool shade(const RtMaterial &M, V3 tex, const Rec &rec, V3 d_in, Rng &g, V3 *o_out, V3 *d_out, V3 *att, V3 *emit,
+                 int ball_iters = 0, bool *pending = nullptr) {
     *emit = mk(0.0, 0.0, 0.0);
-    V3 tex = ld3(M.rgb);
-    if (TEXTURED && !M.solid) tex = texture_value(L, M.tex, rec.u, rec.v);
     *o_out = rec.p;
     *att = tex;
     const uint32_t kind = M.kind;
@@ -695,6 +719,52 @@ RT_HD bool shade(const RtLaunch &L, const RtMaterial &M, const Rec &rec, V3 d_in
     return true;
 }
 
+// uv of the hit on primitive `pi` at parameter t, on its own: the record the shading needs is built WITHOUT uv, and a hit
+// whose texture reads them (checker / image) gets them here first, then its Texture::value -- the atan2 / acos / sin
+// evaluations then run while only the path state is live, not the record and the scatter temporaries as well (the
+// kernel with media and textures drops from 225 to below 168 VGPRs: 3 waves per SIMD instead of 2).  Same arithmetic
+// as the record: p = o' + d' t in the primitive's frame, unitSphereUv(p / r) (src/geometry.rs:66-70) or the
+// rectangle's ((x + w/2) / w, (y + h/2) / h) (src/geometry.rs:170-174); a medium's uv are the sums over its boundary
+// hits (src/volume.rs:64-66) and come out of the full medium test.
+template <bool GENERAL, int MEDIUM>
+RT_HD void prim_uv(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double t, SegCtx &sc, double *u, double *v) {
+    const RtPrimGeo &G = L.prim_geo[pi];
+    *u = 0.0;
+    *v = 0.0;
+    uint32_t kw = (uint32_t)RT_PRIM_SPHERE_T;
+    if (GENERAL || MEDIUM) kw = L.prim_meta[pi].kind;
+    const uint32_t kind = kw & 0xFFu;
+    if (kind == RT_PRIM_SPHERE_T) {
+        const V3 oc = o - mk(G.g[0], G.g[1], G.g[2]);
+        sphere_uv((oc + d * t) / G.g[3], u, v);
+        return;
+    }
+    if (GENERAL || MEDIUM) {
+        if (kind == RT_PRIM_MEDIUM_T || kind == RT_PRIM_MEDIUM_C) {
+            if (MEDIUM >= 2) { // scenes with a textured medium are served by the general-media kernel
+                Rec r;
+                if (prim_hit<GENERAL, MEDIUM, true>(L, pi, o, d, dot(d, d), sc, &r, true)) {
+                    *u = r.u;
+                    *v = r.v;
+                }
+            }
+            return;
+        }
+        const RtPrimMeta &P = L.prim_meta[pi];
+        V3 lo = o, ld = d;
+        chain_down(L, P.xform, (kw >> RT_META_CHAIN_SHIFT) & 7u, (kw >> RT_META_TMASK_SHIFT) & 0xFu, &lo, &ld);
+        if (kind == RT_PRIM_SPHERE_C) {
+            sphere_uv((lo + ld * t) / G.g[0], u, v);
+        } else {
+            Rec r;
+            if (rect_hit(lo, ld, G.g[0], G.g[1], &r)) {
+                *u = r.u;
+                *v = r.v;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- path state
 struct PathState {
     // Only DiffuseLight emits and it never scatters (src/material.rs:17-20,291-297), so the
@@ -758,26 +828,32 @@ RT_HD bool finish_segment(const RtLaunch &L, PathState *ps, const Trav &tv, V3 *
     const uint32_t mat = L.prim_meta[prim].material;
     if (mat == RT_NO_MATERIAL) return true; // src/render.rs:18-20
     const RtMaterial &M = L.materials[mat];
-    // uv feeds nothing but Texture::value (src/material.rs:196-198): needed iff the material's texture is not a solid colour
-    const bool uv = TEXTURED && !M.solid;
+    SegCtx sc;
+    sc.rng_base = ps->g.base;
+    sc.segment = (uint32_t)ps->k;
+    sc.draws = 0;
+    sc.prims_tested = 0;
+    // Texture::value first (src/material.rs:196-198); uv feed nothing else, so they are evaluated only when the
+    // material's texture is not a solid colour -- the reference computes atan2 / acos on every sphere hit
+    V3 tex = ld3(M.rgb);
+    if (TEXTURED && !M.solid) {
+        double u, v;
+        prim_uv<GENERAL, MEDIUM>(L, prim, ps->o, ps->d, tv.best_t, sc, &u, &v);
+        tex = texture_value(L, M.tex, u, v);
+    }
     Rec rec;
     if (GENERAL || MEDIUM) {
-        SegCtx sc;
-        sc.rng_base = ps->g.base;
-        sc.segment = (uint32_t)ps->k;
-        sc.draws = 0;
-        sc.prims_tested = 0;
-        // rebuild the full record of the winner (same arithmetic, same t, same keyed draws)
-        prim_hit<GENERAL, MEDIUM, true>(L, prim, ps->o, ps->d, dot(ps->d, ps->d), sc, &rec, uv);
+        // rebuild the record of the winner (same arithmetic, same t, same keyed draws)
+        prim_hit<GENERAL, MEDIUM, true>(L, prim, ps->o, ps->d, dot(ps->d, ps->d), sc, &rec, false);
     } else {
         const RtPrimGeo &G = L.prim_geo[prim];
         V3 c = mk(G.g[0], G.g[1], G.g[2]);
-        sphere_finish(ps->o - c, ps->d, G.g[3], tv.best_t, uv, &rec);
+        sphere_finish(ps->o - c, ps->d, G.g[3], tv.best_t, false, &rec);
         rec.p = rec.p + c;
     }
     V3 o2, d2, att, emit;
     bool pend = false;
-    const bool cont = shade<TEXTURED>(L, M, rec, ps->d, ps->g, &o2, &d2, &att, &emit, ball_iters, &pend);
+    const bool cont = shade(M, tex, rec, ps->d, ps->g, &o2, &d2, &att, &emit, ball_iters, &pend);
     if (pend) {
         *pending = true;
         return false;

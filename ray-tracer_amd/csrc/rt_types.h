@@ -129,6 +129,7 @@ struct RtLaunch {
     const uint8_t *image_blob;
     int32_t n_nodes;
     int32_t stack_entries; // LDS stack entries per lane for this scene (tree depth + 1, <= RT_STACK_DEPTH)
+    int32_t swap_cap;      // entries per class queue of the swap-at-shade queues (rt_kernels.hip)
     uint32_t root;      // 16-bit reference of the BVH root, or RT_CUR_DONE when every prim is hoisted
     int32_t n_hoisted;  // prims [0, n_hoisted) are tested directly for every segment
     int32_t n_prims;

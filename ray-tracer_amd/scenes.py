@@ -305,3 +305,59 @@ def build_product(desc: SceneDesc, device: int = 0):
     sc.commit(device)
     cam = rt.Camera(*desc.camera)
     return sc, cam
+
+
+# ------------------------------------------------------------------ instancing
+def instanced(aspect: float = 1.0, seed: int = 1) -> SceneDesc:
+    """Not one of the reference's examples: what its API allows beyond them.  A cluster of spheres, a rectangle and a cube
+    (a BoundingVolumeHierarchyNode used as a sprite's GEOMETRY, src/sprite.rs:87-93) instanced three times under rotated /
+    scaled transforms, one instance of instances (four transform levels above the cube faces), the book's Cornell smoke
+    boxes (ConstantMedium over a rotated cube and over a node of two spheres, src/volume.rs:40-100), one of them instanced twice
+    (media keyed per instance), a ConstantMedium behind a TransformedGeometry, a checker-textured medium, and a child that
+    carries a material of its own (replaced by the instancing sprite's, src/sprite.rs:119-127)."""
+    d = SceneDesc(name="instanced")
+    g = HostRng(seed)
+    ex, ey, ez = (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)
+
+    def tr(t, rad=0.0, axis=ey):
+        return mat4_multiplied(mat4_translation(t), mat4_rotation(rad, axis))
+
+    white = d.lambertian_rgb((0.73, 0.73, 0.73))
+    red = d.lambertian_rgb((0.65, 0.05, 0.05))
+    glass = d.mat("dielectric", 1.5)
+    steel = d.mat("metal", d.tex_solid((0.8, 0.8, 0.9)), 0.2)
+    d.textures.append(("checker", d.tex_solid((0.1, 0.1, 0.4)), d.tex_solid((0.9, 0.9, 0.9))))
+    checker = len(d.textures) - 1
+    # the cluster: five small spheres, a rectangle, a cube (children; the red one's own material is never seen)
+    kids = []
+    s_small = d.geom("sphere", 0.4)
+    for _ in range(5):
+        kids.append(d.sprite(s_small, None, mat4_translation((g.gen_range(-1.0, 1.0), g.gen_range(-1.0, 1.0), g.gen_range(-1.0, 1.0)))))
+    kids.append(d.sprite(d.geom("rectangle", 2.5, 1.0), red, tr((0.0, -1.2, 0.0), radians(-90.0), ex)))
+    kids.append(d.sprite(d.geom("cube", 0.8, 1.2, 0.6), None, tr((0.9, 0.3, -0.8), 0.5, ey)))
+    cluster = d.geom("bvh", kids)
+    scale = [1.6, 0.0, 0.0, 0.0, 0.0, 0.7, 0.0, 0.0, 0.0, 0.0, 1.1, 0.0, 0.0, 0.0, 0.0, 1.0]  # non-rigid on purpose (quirk Q5)
+    c1 = d.sprite(cluster, white, tr((-4.0, 1.5, 2.0), 0.3, ey))
+    c2 = d.sprite(cluster, steel, mat4_multiplied(tr((0.0, 1.8, 3.5), -0.8, ez), scale))
+    c3 = d.sprite(cluster, glass, tr((4.0, 1.5, 2.0), 1.1, ex))
+    # an instance of instances: two clusters under one more node, placed twice
+    pair = d.geom("bvh", [d.sprite(cluster, None, tr((-1.5, 0.0, 0.0), 0.2, ey)), d.sprite(cluster, None, tr((1.5, 0.4, 0.0), -0.4, ez))])
+    p1 = d.sprite(pair, white, tr((-2.5, 5.0, 6.0), 0.6, ey))
+    p2 = d.sprite(pair, steel, tr((3.0, 5.5, 7.0), -0.9, ex))
+    # smoke: over a rotated cube, over a node of two spheres (instanced twice), behind a TransformedGeometry, textured
+    smoke_dark = d.mat("isotropic", d.tex_solid((0.05, 0.05, 0.05)))
+    smoke_light = d.mat("isotropic", d.tex_solid((0.95, 0.95, 0.95)))
+    m1 = d.sprite(d.geom("medium", d.geom("cube", 1.6, 2.4, 1.6), 0.9), smoke_dark, tr((-2.0, 1.2, -1.0), radians(15.0), ey))
+    two = d.geom("bvh", [d.sprite(d.geom("sphere", 0.8), None, mat4_translation((-0.5, 0.0, 0.0))),
+                         d.sprite(d.geom("sphere", 0.6), None, mat4_translation((0.6, 0.2, 0.0)))])
+    blob = d.geom("bvh", [d.sprite(d.geom("medium", two, 1.5), None, tr((0.0, 0.0, 0.0), 0.3, ez))])
+    m2 = d.sprite(blob, smoke_light, tr((1.8, 0.9, -1.2), 0.4, ey))
+    m3 = d.sprite(blob, smoke_dark, tr((3.6, 1.0, -0.2), -0.7, ex))
+    m4 = d.sprite(d.geom("transformed", d.geom("medium", d.geom("sphere", 0.7), 1.2), tr((0.0, 0.3, 0.0), 0.9, ex)),
+                  d.mat("isotropic", checker), tr((0.0, 0.8, -2.0), 0.2, ey))
+    floor = d.sprite(d.geom("rectangle", 40.0, 40.0), d.mat("lambertian", checker), tr((0.0, 0.0, 0.0), radians(-90.0), ex))
+    lamp = d.sprite(d.geom("rectangle", 6.0, 6.0), d.mat("diffuse_light", d.tex_solid((6.0, 6.0, 6.0))), tr((0.0, 9.0, 2.0), radians(90.0), ex))
+    sky = d.sprite(d.geom("sphere", 80.0), d.mat("diffuse_light", d.tex_solid((0.25, 0.3, 0.4))), None)
+    d.world = [c1, c2, c3, p1, p2, m1, m2, m3, m4, floor, lamp, sky]
+    d.camera = ((0.0, 4.0, -11.0), (0.0, 2.0, 2.0), (0.0, 1.0, 0.0), radians(45.0), float(aspect), 10.0, 0.0)
+    return d

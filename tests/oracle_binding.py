@@ -40,6 +40,8 @@ _sig("orc_geom_sphere", _I, [_VP, _D])
 _sig("orc_geom_rectangle", _I, [_VP, _D, _D])
 _sig("orc_geom_cube_bvh", _I, [_VP, _D, _D, _D, _U64])
 _sig("orc_geom_constant_medium", _I, [_VP, _I, _D])
+_sig("orc_geom_bvh", _I, [_VP, _IP, _I, _U64])
+_sig("orc_geom_transformed", _I, [_VP, _I, _DP])
 _sig("orc_sprite", _I, [_VP, _I, _I, _DP])
 _sig("orc_object_bvh", _I, [_VP, _IP, _I, _U64])
 _sig("orc_world_bvh", _I, [_VP, _IP, _I, _U64])
@@ -127,21 +129,36 @@ def build_oracle(desc, bvh_seed=7, world="bvh") -> OracleScene:
         seed[0] += 1
         return seed[0]
 
-    for g in desc.geometries:
-        if g[0] == "sphere":
-            LIB.orc_geom_sphere(h, g[1])
-        elif g[0] == "rectangle":
-            LIB.orc_geom_rectangle(h, g[1], g[2])
-        elif g[0] == "cube":
-            LIB.orc_geom_cube_bvh(h, g[1], g[2], g[3], next_seed())
-        elif g[0] == "medium":
-            LIB.orc_geom_constant_medium(h, g[1], g[2])
-        else:
-            raise ValueError(g[0])
-    sprite_obj = []
+    # geometries on demand (a node geometry needs its sprites first), sprites strictly in description order: their
+    # creation indices key the draws of instanced media exactly as in the product (include/rt_rng.h)
+    gid, sprite_obj, owned = {}, [], set()
+
+    def geometry(i):
+        if i is None:
+            return -1
+        if i not in gid:
+            g = desc.geometries[i]
+            if g[0] == "sphere":
+                gid[i] = LIB.orc_geom_sphere(h, g[1])
+            elif g[0] == "rectangle":
+                gid[i] = LIB.orc_geom_rectangle(h, g[1], g[2])
+            elif g[0] == "cube":
+                gid[i] = LIB.orc_geom_cube_bvh(h, g[1], g[2], g[3], next_seed())
+            elif g[0] == "medium":
+                gid[i] = LIB.orc_geom_constant_medium(h, geometry(g[1]), g[2])
+            elif g[0] == "transformed":
+                gid[i] = LIB.orc_geom_transformed(h, geometry(g[1]), dp(np.ascontiguousarray(g[2], dtype=np.float64)))
+            elif g[0] == "bvh":
+                kids = [sprite_obj[c] for c in g[1]]
+                owned.update(g[1])
+                gid[i] = LIB.orc_geom_bvh(h, (C.c_int * len(kids))(*kids), len(kids), next_seed())
+            else:
+                raise ValueError(g[0])
+        return gid[i]
+
     for (gi, mi, M) in desc.sprites:
         m = None if M is None else dp(np.ascontiguousarray(M, dtype=np.float64))
-        sprite_obj.append(LIB.orc_sprite(h, -1 if gi is None else gi, -1 if mi is None else mi, m))
+        sprite_obj.append(LIB.orc_sprite(h, geometry(gi), -1 if mi is None else mi, m))
 
     def ids(entries):
         out = []
@@ -154,7 +171,7 @@ def build_oracle(desc, bvh_seed=7, world="bvh") -> OracleScene:
                 out.append(sprite_obj[e])
         return out
 
-    top = ids(desc.world if desc.world is not None else list(range(len(desc.sprites))))
+    top = ids(desc.world if desc.world is not None else [i for i in range(len(desc.sprites)) if i not in owned])
     arr = (C.c_int * len(top))(*top)
     if world == "bvh":
         rc = LIB.orc_world_bvh(h, arr, len(top), bvh_seed)

@@ -109,3 +109,41 @@ def test_bounded_ball_sampler_is_the_same_loop(lane_emul):
     assert most >= 4
     calls, p, q, a, b = lane_emul.ball_check(7, 5, 0)  # 0 = unbounded
     assert calls == 1 and np.array_equal(p, q) and a == b
+
+
+def test_instanced_nodes_and_general_media_exact(scenes, oracle, lane_emul):
+    """A BoundingVolumeHierarchyNode as a sprite's geometry (instancing, src/sprite.rs:87-93), instances of instances (four
+    transform levels), ConstantMedium over a cube / over a node of spheres / behind a TransformedGeometry
+    (src/volume.rs:40-100), media instanced twice (keyed per instance): the expanded flat scene against the oracle's
+    recursive trait-object walk, bit for bit."""
+    d = scenes.instanced(1.25)
+    sc, cam = scenes.build_product(d, device=-1)
+    info = sc.info()
+    # 3 clusters x (5 + 1 + 6) + 2 pairs x 2 x 12 leaves, 4 media, floor, lamp, sky; boundary prims: 6 + 2 + 2 + 1
+    assert info["n_prims"] == 3 * 12 + 2 * 24 + 4 + 3 and info["n_child_prims"] == 6 + 2 + 2 + 1
+    assert info["feature_mask"] & rt_feat(scenes, "RT_FEAT_MEDIUM_GENERAL")
+    img, cnt, high = lane_emul.render(sc, cam, 50, 40, 6, 60, 3)
+    ref, ocnt = oracle.build_oracle(d).render(50, 40, 6, 60, 3, iterative=True, nthreads=8, counters=True)
+    assert np.array_equal(img, ref)
+    assert cnt["segments"] == ocnt["segments"]
+    assert img.std() > 0.05
+    # the tree and the world's form do not matter (F7), nested nodes included
+    for kw in ({"bvh_seed": 99}, {"world": "list"}):
+        assert np.array_equal(img, oracle.build_oracle(d, **kw).render(50, 40, 6, 60, 3, iterative=True, nthreads=8))
+
+
+def rt_feat(scenes, name):
+    import sys
+    return getattr(sys.modules["ray_tracer_amd"], name)
+
+
+def test_chain_depth_limit_is_reported(rt, scenes):
+    """five transform levels above a sphere: outside RT_MAX_CHAIN, an error at commit, never a wrong picture"""
+    s = rt.Scene()
+    node = s.bvh([s.sprite(s.sphere(1.0), None, scenes.mat4_rotation(0.1, (0.0, 1.0, 0.0)))])
+    for _ in range(3):
+        node = s.bvh([s.sprite(node, None, scenes.mat4_rotation(0.1, (0.0, 1.0, 0.0)))])
+    s.sprite(node, None, scenes.mat4_rotation(0.1, (0.0, 1.0, 0.0)))
+    with pytest.raises(rt.RtError) as e:
+        s.commit(-1)
+    assert e.value.code == -4 and "transform levels" in str(e.value)
