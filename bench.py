@@ -12,6 +12,18 @@ HBM before the timed region.
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+The JSON line carries
+  roofline      what bounds render_kernel: VALU issue.  The scene (< 1 MB) lives in LDS / L1 / L2, so HBM is not the
+                roof (0.27 TB/s of real traffic = 3 % of peak; the algorithmic bytes of SURVEY.md 8(d) are kept as the
+                secondary "hbm_equivalent" object).  achieved = sum over instruction classes of (wave instructions per
+                launch, rocprofv3 SQ_INSTS_VALU_* of profiles/r02_<scene>/summary.json) x (issue cycles per instruction
+                per SIMD measured on the MI355X, profiles/r02_valu_issue.json) / (kernel duration measured live here
+                with HIP events); peak = 1024 SIMDs x 2.4 GHz.  The counts are only used when the profile was taken
+                with THIS build of the library (rt_version source hash) on this workload; otherwise frac is null.
+  cpu_baseline  the oracle in reference form on the host cores, on a bounded sample of the same workload.
+With N > 1 every rank also reports render / gather / unpack / copy times of one extra, untimed step, and rank 0 checks the
+gathered image against a single-GPU render of the whole image.
 """
 import argparse
 import importlib
@@ -24,7 +36,11 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+N_SIMD = 256 * 4        # 256 CUs x 4 SIMDs
+MAX_CLOCK_GHZ = 2.4     # same table: max clock 2400 MHz
+BASELINE_CONFIGS = {("book_one", 1200, 800, 500): "configs[1]", ("cornell", 600, 600, 1000): "configs[2]",
+                    ("cover", 800, 800, 1000): "configs[3]", ("book_one", 3840, 2160, 2000): "configs[4]"}
 
 
 def parse():
@@ -45,13 +61,14 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path on a box with fewer GPUs (shards staged through host memory)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
-    ap.add_argument("--check", action="store_true", help="rank 0 also renders the whole image alone and compares")
+    ap.add_argument("--check", action="store_true", help="rank 0 also renders the whole image alone and compares (default for N > 1)")
+    ap.add_argument("--no-check", action="store_true", help="skip that comparison for N > 1")
     ap.add_argument("--pipeline", action="store_true",
                     help="experiment: consecutive steps on two alternating streams (measured slower, see DESIGN.md section 8)")
     return ap.parse_args()
 
 
-def cpu_baseline(desc, W, H, depth, seed, target_s):
+def cpu_baseline(desc, name, W, H, spp_full, depth, seed, target_s):
     """The oracle in reference form (recursive unpruned BVH, 4x4 per sprite, uv on every hit),
     threaded like the example drivers, on a bounded sample of the same workload."""
     sys.path.insert(0, str(ROOT / "tests"))
@@ -66,8 +83,48 @@ def cpu_baseline(desc, W, H, depth, seed, target_s):
     o.render(W, H, spp, depth, seed, nthreads=cores)
     dt = time.perf_counter() - t0
     return {"value": W * H * spp / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"book-one {W}x{H} at {spp} spp (of 500), depth {depth}, whole image, {dt:.1f} s; "
+            "sample": f"{name} {W}x{H} at {spp} spp (of {spp_full}), depth {depth}, whole image, {dt:.1f} s; "
                       f"oracle reference form, {cores} threads dealt rows y % n like examples/book-one.rs:56-65"}
+
+
+def issue_roofline(rt, scene, W, H, spp, depth, world, kernel_ms, lane_util):
+    """VALU-issue roofline of render_kernel from the committed rocprofv3 summary of this workload, if it belongs to this build."""
+    out = {"bound": "valu_issue", "achieved": None, "peak": N_SIMD * MAX_CLOCK_GHZ, "unit": "Gcycle/s (VALU issue cycles, all 1024 SIMDs)",
+           "frac": None, "useful_frac": None, "traffic": None, "source": None}
+    prof = ROOT / "profiles" / f"r02_{scene}" / "summary.json"
+    if world != 1:
+        out["reason"] = "instruction counts are profiled on the whole image (N = 1) only"
+        return out
+    if not prof.exists():
+        out["reason"] = f"no committed profile {prof.relative_to(ROOT)}"
+        return out
+    s = json.load(open(prof))
+    want = f"--scene {scene} --width {W} --height {H} --spp {spp}"
+    if want not in s.get("command", "") or depth != 100:
+        out["reason"] = f"{prof.relative_to(ROOT)} was taken on another workload ({s.get('command')})"
+        return out
+    if s.get("library") != rt.version():
+        out["reason"] = f"{prof.relative_to(ROOT)} was taken with another build ({s.get('library')}) than the loaded {rt.version()}"
+        return out
+    v = s.get("valu_issue_roofline")
+    if not v:
+        out["reason"] = "profile has no instruction-class counters"
+        return out
+    issue = v["issue_cycles_total"]                      # issue cycles per launch (class counts x measured prices)
+    achieved = issue / (kernel_ms * 1e-3) / 1e9          # with the kernel duration measured live in this run
+    out.update({"achieved": achieved, "frac": achieved / out["peak"], "useful_frac": achieved / out["peak"] * lane_util,
+                "traffic": (s.get("hbm_traffic_bytes_per_launch") or {}).get("total"),
+                "source": f"{prof.relative_to(ROOT)} (rocprofv3 --pmc passes of `{s['command']}`, build {rt.build_hash()}); "
+                          f"prices profiles/r02_valu_issue.json; kernel_ms live (HIP events)",
+                "issue_cycles_per_launch": issue, "wave_instructions_per_launch": v["wave_instructions_per_launch"],
+                "issue_cycles_per_instruction": v["issue_cycles_per_instruction"],
+                "profiled_kernel_ms": s.get("render_kernel_avg_ms"), "profiled_clock_ghz": v.get("clock_ghz"),
+                "profiled_frac_at_measured_clock": v.get("frac"), "valu_lane_utilisation_pmc": s.get("valu_lane_utilisation"),
+                "lds_conflict_share": s.get("lds_conflict_share_of_lds_active"), "wave_cycle_shares": s.get("wave_cycle_shares"),
+                "note": "frac = VALU issue slots of the whole chip filled during the launch; useful_frac weights it with the lane "
+                        "utilisation of the wave-vote blocks (live counters); >= 0.9 means the kernel can only get faster by "
+                        "executing fewer instructions or wasting fewer lanes"})
+    return out
 
 
 def main():
@@ -89,11 +146,23 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
+        # the communicator comes up -- and is exercised once -- BEFORE any render, so that an RCCL failure cannot be
+        # mistaken for a kernel failure (and the other way round)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        try:
+            if a.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                probe = torch.ones(1, device=dev)
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                probe = torch.ones(1)
+            dist.all_reduce(probe)
+            if a.backend == "nccl":
+                torch.cuda.synchronize()
+            assert int(probe.item()) == world
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench rank {rank}] communicator ({a.backend}) failed before any render: {e!r}", file=sys.stderr, flush=True)
+            raise
 
     rt = load_package()
     scenes = importlib.import_module("ray_tracer_amd.scenes")
@@ -126,14 +195,24 @@ def main():
     copy_done = [torch.cuda.Event() for _ in range(2)] if rank == 0 else None
     step_no = [0]
 
-    def step():
+    def step(marks=None):
+        """one render of the whole image; marks (optional) collects CUDA events after render / gather / unpack / copy"""
         k = step_no[0]
         step_no[0] += 1
         rs = render_streams[k % n_buf]
         mine_k, gathered_k = mines[k % n_buf], gathereds[k % n_buf]
+
+        def mark(name, stream_obj):
+            if marks is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(stream_obj)
+                marks.append((name, e))
+
         with torch.cuda.stream(rs):
             stream = rs.cuda_stream
+            mark("start", rs)
             sc.render_tiles_device(cam, W, H, spp, depth, a.seed, (rank, world), mine_k.data_ptr(), None, stream)
+            mark("render", rs)
             if world > 1 and a.backend == "nccl":
                 glist = list(gathered_k.chunk(world)) if rank == 0 else None
                 dist.gather(mine_k, glist, dst=0)  # the one collective of the path (RCCL over xGMI)
@@ -143,17 +222,20 @@ def main():
                 dist.gather(hm, hl, dst=0)
                 if rank == 0:
                     gathered_k.copy_(torch.cat(hl))
+            mark("gather", rs)
             if rank == 0:
                 b = k & 1
                 src = gathered_k if world > 1 else mine_k
                 rs.wait_event(copy_done[b])  # the copy that last read images[b] has finished
                 rt.unpack_tiles_device(src.data_ptr(), pad_tiles, world, W, H, images[b].data_ptr(), stream)
+                mark("unpack", rs)
                 unpacked = torch.cuda.Event()
                 unpacked.record(rs)
                 copy_stream.wait_event(unpacked)
                 with torch.cuda.stream(copy_stream):
                     host_images[b].copy_(images[b], non_blocking=True)
                     copy_done[b].record(copy_stream)
+                    mark("d2h", copy_stream)
 
     def sync():
         if world > 1:
@@ -170,6 +252,15 @@ def main():
     dt = time.perf_counter() - t0
     last_kernel_ms = sc.last_kernel_ms()
 
+    # one more, UNTIMED step with events after every stage (per-rank anatomy of a step)
+    marks = []
+    step(marks)
+    sync()
+    anatomy = {}
+    for (n0, e0), (n1, e1) in zip(marks, marks[1:]):
+        anatomy[n1 + "_ms"] = e0.elapsed_time(e1)
+    anatomy["render_kernel_ms"] = sc.last_kernel_ms()
+
     # per-launch kernel duration measured with HIP events on the launch stream: time each launch separately, untimed loop
     per_launch = []
     for _ in range(max(1, min(a.steps, 3))):
@@ -180,8 +271,13 @@ def main():
     launch_cfg = sc.last_launch_config()
 
     tmax = torch.tensor([dt, kernel_avg_ms], dtype=torch.float64, device=dev)
+    per_rank = None
     if world > 1:
+        if a.backend == "gloo":
+            tmax = tmax.cpu()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        per_rank = [None] * world if rank == 0 else None
+        dist.gather_object(dict(anatomy, rank=rank, device=local_rank, tiles=n_tiles[rank]), per_rank, dst=0)
     dt = float(tmax[0])
     kernel_avg_ms = float(tmax[1])
 
@@ -196,44 +292,43 @@ def main():
         bytes_per_sample = (cnt["nodes_visited"] * info["node_bytes"] + cnt["prims_tested"] * info["prim_bytes"]
                             + cnt["segments"] * info["material_bytes"]) / ns + 24.0 / spp
         launch_samples = total_samples / world
-        achieved = bytes_per_sample * launch_samples / (kernel_avg_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes of this same command,
-        # tools/profile.sh; corrected as MI355X_MICROARCH.md prescribes); only valid for the profiled workload
-        traffic, valu = None, None
-        tf = ROOT / "profiles" / "pmc_traffic.json"
-        if tf.exists() and (a.scene, W, H, spp, depth, world) == ("book_one", 1200, 800, 500, 100, 1):
-            pmc = json.load(open(tf))
-            traffic = pmc["hbm_bytes_per_launch"]
-            valu = pmc.get("valu")  # what actually bounds the kernel (same profile): VALU issue
+        hbm_equiv = bytes_per_sample * launch_samples / (kernel_avg_ms * 1e-3) / 1e9
+        util = {b: cnt[b + "_lane"] / max(1, 64 * cnt[b + "_wave"]) for b in ("node", "leaf", "shade")}
+        cyc = {b: cnt[b + "_cycles"] / max(1, cnt["node_cycles"] + cnt["leaf_cycles"] + cnt["shade_cycles"])
+               for b in ("node", "leaf", "shade", "finish", "refill", "begin", "swap")}
+        lane_util = sum(util[b] * cyc[b] for b in ("node", "leaf", "shade"))  # cycle-weighted lane utilisation of the vote blocks
+        roof = issue_roofline(rt, a.scene, W, H, spp, depth, world, kernel_avg_ms, lane_util)
+        roof.update({
+            "kernel": "render_kernel", "kernel_ms": kernel_avg_ms, "launch": launch_cfg,
+            "hbm_equivalent": {"algorithmic_bytes_per_sample": bytes_per_sample, "achieved_GBs": hbm_equiv, "peak_GBs": HBM_PEAK_GBS,
+                               "frac": hbm_equiv / HBM_PEAK_GBS,
+                               "note": "SURVEY.md 8(d) algorithmic bytes (node steps x 64 B + prim tests x 32 B + segments x 48 B + 24 B / spp); "
+                                       "they are served by LDS / L1 / L2, so this is NOT a bound (it exceeds the HBM peak)"},
+            "segments_per_sample": cnt["segments"] / ns, "nodes_per_sample": cnt["nodes_visited"] / ns,
+            "prims_per_sample": cnt["prims_tested"] / ns, "simd_utilisation": util, "lane_utilisation_cycle_weighted": lane_util,
+            "block_executions_per_sample": {b: cnt[b + "_wave"] * 64 / ns for b in ("node", "leaf", "shade")},
+            "block_cycle_share": cyc,
+            "swap_at_shade": ({k[5:]: cnt[k] for k in cnt if k.startswith("swap_")} if cnt.get("swap_scattered") else None)})
+        cfg_name = BASELINE_CONFIGS.get((a.scene, W, H, spp))
+        scene_words = {"book_one": "book-one random-spheres", "cornell": "cornell-box", "cover": "book-two cover (main.rs)"}[a.scene]
         res = {
             "metric": "Msamples/sec (pixels x spp), book-one 1200x800x500spp" if a.scene == "book_one" else f"Msamples/sec (pixels x spp), {a.scene}",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"book-one random-spheres {W}x{H}, {spp} spp, depth {depth} (BASELINE.json configs[1])"
-                                    if a.scene == "book_one" else f"{a.scene} {W}x{H}, {spp} spp, depth {depth}"),
-                       "scene_seed": a.scene_seed, "render_seed": a.seed, "n_spheres": info["n_prims"],
+            "config": {"workload": f"{scene_words} {W}x{H}, {spp} spp, depth {depth}" + (f" (BASELINE.json {cfg_name})" if cfg_name else ""),
+                       "scene_seed": a.scene_seed, "render_seed": a.seed, "n_prims": info["n_prims"],
                        "bvh_nodes": info["n_nodes"], "sharding": f"8x8 tiles, tile_id % {world}, one RCCL gather",
-                       "steps_pipelined_on_two_streams": bool(a.pipeline)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu_pmc": valu,
-                         "note": "algorithmic bytes are served from LDS/L1/L2 (scene < 100 KB): the kernel is VALU-issue bound, see DESIGN.md",
-                         "kernel": "render_kernel", "kernel_ms": kernel_avg_ms, "launch": launch_cfg, "algorithmic_bytes_per_sample": bytes_per_sample,
-                         "segments_per_sample": cnt["segments"] / ns, "nodes_per_sample": cnt["nodes_visited"] / ns,
-                         "prims_per_sample": cnt["prims_tested"] / ns,
-                         "simd_utilisation": {b: cnt[b + "_lane"] / max(1, 64 * cnt[b + "_wave"]) for b in ("node", "leaf", "shade")},
-                         "block_executions_per_sample": {b: cnt[b + "_wave"] * 64 / ns for b in ("node", "leaf", "shade")},
-                         "block_cycle_share": {b: cnt[b + "_cycles"] / max(1, cnt["node_cycles"] + cnt["leaf_cycles"] + cnt["shade_cycles"])
-                                               for b in ("node", "leaf", "shade", "finish", "refill", "begin", "swap")},
-                         "swap_at_shade": ({k[5:]: cnt[k] for k in cnt if k.startswith("swap_")} if cnt.get("swap_scattered") else None)},
-            "wall_s": dt, "last_kernel_ms": last_kernel_ms,
+                       "library": rt.version(), "steps_pipelined_on_two_streams": bool(a.pipeline)},
+            "roofline": roof, "wall_s": dt, "last_kernel_ms": last_kernel_ms,
+            "step_anatomy_ms": per_rank if per_rank is not None else [dict(anatomy, rank=0, device=local_rank, tiles=n_tiles[0])],
         }
-        if a.check:
+        if (world > 1 and not a.no_check) or a.check:
             whole = sc.render(cam, W, H, spp, depth, a.seed)
             last = host_images[(step_no[0] - 1) & 1]
             res["image_matches_single_gpu"] = bool(np.array_equal(last.numpy().reshape(H, W, 3), whole))
         if not a.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(desc, W, H, depth, a.seed, a.cpu_seconds)
+            res["cpu_baseline"] = cpu_baseline(desc, scene_words, W, H, spp, depth, a.seed, a.cpu_seconds)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))

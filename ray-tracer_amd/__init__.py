@@ -378,6 +378,28 @@ def tonemap_png8(img: np.ndarray) -> np.ndarray:
     return out
 
 
+HASHED_SOURCES = ("csrc/rt_kernels.hip", "csrc/rt_lane.h", "csrc/rt_types.h", "csrc/rt_host.cpp", "csrc/rt_host.h", "csrc/rt_api.cpp",
+                  "csrc/rt_scene_priv.h", "../include/rt_mi355x.h", "../include/rt_rng.h", "csrc/Makefile")
+
+
+def version() -> str:
+    return lib().rt_version().decode()
+
+
+def build_hash() -> str:
+    """source hash the loaded library was built from (rt_version)"""
+    return version().rsplit("src ", 1)[-1]
+
+
+def source_hash() -> str:
+    """the same hash computed from the tree (csrc/Makefile: SRC_HASH)"""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in HASHED_SOURCES:
+        h.update((_HERE / rel).read_bytes())
+    return h.hexdigest()[:16]
+
+
 def device_count() -> int:
     return int(lib().rt_device_count())
 

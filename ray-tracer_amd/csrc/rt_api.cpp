@@ -67,7 +67,10 @@ int upload(const std::vector<T> &v, void **dptr, size_t *total) {
 extern "C" {
 
 const char *rt_last_error(void) { return g_err.c_str(); }
-const char *rt_version(void) { return "rt_mi355x 0.1 (gfx950, f64)"; }
+#ifndef RT_SOURCE_HASH
+#define RT_SOURCE_HASH "unknown"
+#endif
+const char *rt_version(void) { return "rt_mi355x 0.2 (gfx950, f64) src " RT_SOURCE_HASH; }
 
 int rt_device_count(void) {
     int n = 0;

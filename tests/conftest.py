@@ -28,17 +28,23 @@ def load_package():
 
 
 def _make(directory: Path, target_file: Path):
-    """Build a native helper if it is missing (the GPU box receives prebuilt .so files)."""
-    if not target_file.exists():
-        subprocess.run(["make", "-C", str(directory)], check=True, capture_output=True)
+    """Always run make: the Makefiles track their sources, so this is a no-op when the helper is current and a rebuild
+    when an edited kernel / lane header / oracle would otherwise be tested through a stale .so."""
+    r = subprocess.run(["make", "-C", str(directory)], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"make -C {directory} failed:\n{r.stdout}\n{r.stderr}")
     return target_file
 
 
 @pytest.fixture(scope="session")
 def rt():
     mod = load_package()
-    _make(ROOT / "ray-tracer_amd" / "csrc", mod.LIB_PATH)
+    import os
+    if not os.environ.get("RT_MI355X_LIB"):
+        _make(ROOT / "ray-tracer_amd" / "csrc", mod.LIB_PATH)
     mod.lib()
+    if not os.environ.get("RT_MI355X_LIB"):
+        assert mod.build_hash() == mod.source_hash(), "librt_mi355x.so was not built from the sources in this tree"
     return mod
 
 

@@ -10,7 +10,7 @@ summary.json holds, for the timed render_kernel (COUNT = false instantiation):
     instruction per SIMD, measured by tools/microbench/valu_issue.hip -> profiles/r02_valu_issue.json)
     divided by (1024 SIMDs x elapsed shader cycles of the launch, GRBM_GUI_ACTIVE / 8 XCDs),
   * register / scratch / LDS figures of the code object (hipcc -Rpass-analysis=kernel-resource-usage remarks kept in
-    ray-tracer_amd/csrc/_obj/resource_usage.txt, matched by the demangled kernel name) -- rocprofv3's own
+    ray-tracer_amd/csrc/_obj/resource_usage.txt, matched by the demangled kernel name, c++filt) -- rocprofv3's own
     VGPR_Count / LDS_Block_Size columns are wrong for this launch (64 / 0) and are reported only as "rocprof_dispatch_columns".
 
 Usage: summarize_profile.py <prof dir> <tag> [--prices profiles/r02_valu_issue.json]
@@ -33,22 +33,36 @@ DEFAULT_PRICES = {"f32": 2.0, "f64": 4.0, "trans_f32": 8.0, "trans_f64": 16.0, "
                   "source": "defaults from MI355X_MICROARCH.md cycle constants (v_fma_f32 2 cyc/SIMD, f64 half rate); NOT measured"}
 
 
-def load_prices(path):
+def nominal(measured):
+    """pipe occupancy behind a measured issue cost: the microbenchmark sees 2.3-2.4 / 4.15-4.35 / 6.3-8.3 / 16.2 cycles (the
+    pipe's 2 / 4 / 8 / 16 plus a few per cent of issue arbitration); the roofline charges the nominal figure, so that a
+    kernel cannot come out above 1 through prices that were rounded up"""
+    return 2.0 if measured < 3.2 else (4.0 if measured < 5.5 else (8.0 if measured < 10.0 else 16.0))
+
+
+def load_prices(path, waves, other_price):
+    """issue cycles per wave instruction per SIMD of each counter class at `waves` waves per SIMD"""
     p = dict(DEFAULT_PRICES)
     if path and Path(path).exists():
         m = json.load(open(path))
         ins = m["instructions"]
-        w = lambda n: ins[n]["w4"]  # noqa: E731  4 waves per SIMD: the issue-limited rate
+        col = "w%d" % max(1, min(4, int(waves)))
+        w = lambda n: nominal(ins[n][col])  # noqa: E731
+        mean = lambda *ns: sum(w(n) for n in ns) / len(ns)  # noqa: E731
         p = {
-            "f32": max(w("fma_f32"), w("add_f32"), w("mul_f32")),
-            "f64": max(w("fma_f64"), w("add_f64"), w("mul_f64")),
+            "f32": mean("fma_f32", "add_f32", "mul_f32"),
+            "f64": mean("fma_f64", "add_f64", "mul_f64"),
             "trans_f32": w("rcp_f32"),
-            "trans_f64": max(w("rcp_f64"), w("rsq_f64"), w("sqrt_f64")),
-            "int32": max(w("add_u32"), w("xor_b32"), w("lshlrev_b32")),
-            "int64": max(w("lshlrev_b64"), w("lshrrev_b64")),
-            "cvt": max(w("cvt_f64_u32"), w("cvt_f32_f64"), w("cvt_f64_f32")),
-            "other": max(w("mov_b32"), w("cndmask_b32"), w("cmp_f64")),
-            "source": f"{path}: measured on the MI355X by tools/microbench/valu_issue.hip (4 waves per SIMD)",
+            "trans_f64": mean("rcp_f64", "rsq_f64", "sqrt_f64"),
+            # the INT32 counter mixes full-rate (add, and / or / xor, right shifts) and half-rate (left shifts, multiplies,
+            # bit-field, carry) instructions: the mean of the two groups
+            "int32": (mean("add_u32", "xor_b32", "and_b32", "lshrrev_b32") + mean("lshlrev_b32", "mul_lo_u32", "bfe_u32", "add_co_u32")) / 2,
+            "int64": mean("lshlrev_b64", "lshrrev_b64", "mad_u64_u32"),
+            "cvt": mean("cvt_f64_u32", "cvt_f32_f64", "cvt_f64_f32", "cvt_u32_f64"),
+            "other": other_price if other_price else mean("mov_b32", "cndmask_b32_sgpr", "cmp_f64_sgpr"),
+            "source": f"{Path(path).name}: measured on the MI355X by tools/microbench/valu_issue.hip, column {col} "
+                      f"({waves} waves per SIMD), each instruction charged its pipe occupancy 2 / 4 / 8 / 16; 'other' = static-mix average of the unclassified VALU instructions of this kernel "
+                      f"(tools/isa_mix.py)" + ("" if other_price else " -- unavailable, mean of mov / cndmask / cmp used"),
         }
     return p
 
@@ -77,7 +91,7 @@ def code_object_info(demangled_name):
         if m and cur:
             blocks[cur][m.group(1).strip()] = m.group(2)
     try:
-        dem = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"] + list(blocks), capture_output=True, text=True).stdout.split("\n")
+        dem = subprocess.run(["c++filt"] + list(blocks), capture_output=True, text=True).stdout.split("\n")
     except OSError:
         return None
     want = demangled_name.replace(" ", "")
@@ -111,7 +125,9 @@ def main():
                 b = json.loads(line)
                 res["bench_line_of_stats_pass"] = {k: b.get(k) for k in ("value", "unit", "ms_per_step", "config")}
                 res["launch"] = (b.get("roofline") or {}).get("launch")
-    ks = glob.glob(str(out / "stats" / "*" / "*_kernel_stats.csv"))
+                res["library"] = (b.get("config") or {}).get("library")
+    newest = lambda files: sorted(files, key=lambda f: Path(f).stat().st_mtime)[-1:]  # noqa: E731  (merged reruns leave older files behind)
+    ks = newest(glob.glob(str(out / "stats" / "*" / "*_kernel_stats.csv")))
     main_name = None
     if ks:
         shutil.copy(ks[0], dst / "kernel_stats.csv")
@@ -127,7 +143,7 @@ def main():
     for d in sorted(glob.glob(str(out / "pmc*"))):
         if not Path(d).is_dir():
             continue
-        f = glob.glob(d + "/*/*_counter_collection.csv")
+        f = newest(glob.glob(d + "/*/*_counter_collection.csv"))
         if not f:
             continue
         per = collections.defaultdict(list)
@@ -167,7 +183,24 @@ def main():
                "int32": ["SQ_INSTS_VALU_INT32"], "int64": ["SQ_INSTS_VALU_INT64"], "cvt": ["SQ_INSTS_VALU_CVT"]}
     need = [c for cs in classes.values() for c in cs] + ["SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"]
     if all(c in pmc for c in need):
-        prices = load_prices(prices_path)
+        waves = (res.get("launch") or {}).get("waves_per_simd") or 4
+        other_price, other_mix = None, None
+        try:
+            sys.path.insert(0, str(ROOT / "tools"))
+            import isa_mix
+            asm_path = Path("/tmp/rt_kernels_for_profile.s")
+            if not asm_path.exists():
+                src = ROOT / "ray-tracer_amd" / "csrc"
+                subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "--offload-arch=gfx950",
+                                "-mllvm", "-simplifycfg-sink-common=false", "--offload-device-only", "-S", "-o", str(asm_path),
+                                str(src / "rt_kernels.hip")], capture_output=True)
+            key = (res.get("code_object") or {}).get("mangled", "").split("render_kernel")[-1]
+            other_mix = isa_mix.mix(isa_mix.kernel_body(asm_path.read_text(), key))
+            other_price = other_mix["other_price"]
+        except Exception as e:  # noqa: BLE001
+            other_mix = {"error": repr(e)}
+        prices = load_prices(prices_path, waves, other_price)
+        res["static_isa_mix"] = other_mix
         counts = {k: sum(mean(c) for c in cs) for k, cs in classes.items()}
         counts["other"] = max(0.0, mean("SQ_INSTS_VALU") - sum(counts.values()))
         issue = {k: counts[k] * prices[k] for k in counts}
@@ -186,8 +219,8 @@ def main():
             "useful_frac": frac * lane if lane else None,
             "note": "frac = sum(class count x issue cycles) / (1024 SIMDs x elapsed cycles): share of the VALU issue slots of the whole "
                     "chip the launch filled; useful_frac weights it with the VALU lane utilisation (SQ_THREAD_CYCLES_VALU / 64 / "
-                    "SQ_ACTIVE_INST_VALU). 'other' = SQ_INSTS_VALU minus the classified counts (moves, selects, compares), priced as the "
-                    "dearest of v_mov_b32 / v_cndmask_b32 / v_cmp_f64",
+                    "SQ_ACTIVE_INST_VALU). 'other' = SQ_INSTS_VALU minus the classified counts (moves, selects, compares, min / max, "
+                    "lane ops), priced with the static-mix average of those instructions in this kernel's code object",
         }
         if res.get("render_kernel_avg_ms"):
             res["valu_issue_roofline"]["clock_ghz"] = elapsed_cycles / (res["render_kernel_avg_ms"] * 1e-3) / 1e9
