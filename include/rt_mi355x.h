@@ -171,6 +171,17 @@ typedef struct rt_counters {
  * this shard's pixels are written.  counters may be NULL. */
 int rt_render(rt_scene *, const rt_camera *, const rt_render_params *, double *out_rgb, rt_counters *counters);
 
+/* ---- the drivers' thread fan-out and mpsc gather (examples/book-one.rs:52-88) across the GPUs of one node ----
+ * rt_scene_clone: a second committed copy of a recorded scene on another device (the immutable world every worker
+ * thread shares through an Arc upstream, examples/book-one.rs:57-59).
+ * rt_render_sharded: scenes[i] is a committed copy on device i' of its choice; the image is cut into 8x8 tiles dealt
+ * tile_id % n_scenes, all shards are rendered concurrently (one host thread per scene, each on its scene's device and
+ * stream) and every shard's pixels land in out_rgb.  Sample streams are global, so the image is bit-identical for any
+ * n_scenes (params->shard_index / shard_count are ignored).  No collective is involved: this is the entry for callers
+ * that own host memory (the Rust drivers); bench.py keeps the framebuffer on the devices and uses one RCCL gather. */
+rt_scene *rt_scene_clone(const rt_scene *, int device);
+int rt_render_sharded(rt_scene *const *scenes, int n_scenes, const rt_camera *, const rt_render_params *, double *out_rgb);
+
 /* Progressive / resumable rendering (the reference has none: a render is all-or-nothing and a 16.6 Gsample
  * image takes a while).  Renders samples s in [s_begin, s_end) of every pixel of this shard -- the streams are
  * those of the full `params->spp` render -- and continues the raw per-pixel sums in `sums` ([y][x][3], y up)
@@ -242,6 +253,9 @@ int rt_scene_get_info(const rt_scene *, rt_scene_info *out);
  * {lo0[3],hi0[3],lo1[3],hi1[3], child0,child1, culllo0[3],cullhi0[3],culllo1[3],cullhi1[3], -,-};
  * child >= 0 inner node index, child < 0 leaf ~prim; cull* = the binary32 culling boxes */
 int rt_scene_copy_nodes(const rt_scene *, double *out, int max_nodes);
+/* 64-bit FNV-1a over the committed flat scene (prims, transform chains, materials, textures, texels): identifies the
+ * scene a checkpoint of rt_render_progressive belongs to */
+int rt_scene_hash(const rt_scene *, uint64_t *out);
 /* world-space AABB of prim i: {lo[3], hi[3]} */
 int rt_scene_prim_bounds(const rt_scene *, int prim, double out[6]);
 

@@ -112,6 +112,8 @@ ABI = {
     "rt_scene_commit": (C.c_int, [_VP, C.c_int]),
     "rt_camera_perspective": (C.c_int, [C.POINTER(rt_camera), _DP, _DP, _DP, _D, _D, _D, _D]),
     "rt_render": (C.c_int, [_VP, C.POINTER(rt_camera), C.POINTER(rt_render_params), _DP, C.POINTER(rt_counters)]),
+    "rt_scene_clone": (_VP, [_VP, C.c_int]),
+    "rt_render_sharded": (C.c_int, [C.POINTER(_VP), C.c_int, C.POINTER(rt_camera), C.POINTER(rt_render_params), _DP]),
     "rt_render_progressive": (C.c_int, [_VP, C.POINTER(rt_camera), C.POINTER(rt_render_params), C.c_int, C.c_int, _DP]),
     "rt_shard_tile_count": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "rt_render_tiles_device": (C.c_int, [_VP, C.POINTER(rt_camera), C.POINTER(rt_render_params), _VP, _VP, _VP]),
@@ -124,6 +126,7 @@ ABI = {
     "rt_tonemap_png8": (None, [_DP, C.c_size_t, C.POINTER(C.c_uint8)]),
     "rt_scene_get_info": (C.c_int, [_VP, C.POINTER(rt_scene_info)]),
     "rt_scene_copy_nodes": (C.c_int, [_VP, _DP, C.c_int]),
+    "rt_scene_hash": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     "rt_scene_prim_bounds": (C.c_int, [_VP, C.c_int, _DP]),
     "rt_probe_device_math": (C.c_int, [C.c_int, _DP, _DP, C.c_int, _DP, _DP]),
 }
@@ -207,9 +210,16 @@ class Mat4:
 class Scene:
     """Records textures / materials / geometries / sprites through the C ABI."""
 
-    def __init__(self):
-        self._h = lib().rt_scene_create()
-        self.committed = False
+    def __init__(self, handle=None):
+        self._h = handle if handle is not None else lib().rt_scene_create()
+        self.committed = handle is not None
+
+    def clone(self, device: int) -> "Scene":
+        """a second committed copy of this scene on another device (rt_scene_clone)"""
+        h = lib().rt_scene_clone(self._h, device)
+        if not h:
+            raise RtError(-3, lib().rt_last_error().decode())
+        return Scene(h)
 
     def close(self):
         if self._h:
@@ -289,6 +299,11 @@ class Scene:
         _check(lib().rt_scene_get_info(self._h, C.byref(i)))
         return i.as_dict()
 
+    def scene_hash(self) -> int:
+        h = C.c_uint64()
+        _check(lib().rt_scene_hash(self._h, C.byref(h)))
+        return int(h.value)
+
     def nodes(self) -> np.ndarray:
         n = self.info()["n_nodes"]
         out = np.zeros((n, 28))
@@ -340,6 +355,15 @@ class Camera:
         self.args = (tuple(eye), tuple(center), tuple(up), float(fov), float(aspect), float(focus_distance), float(lens_radius))
         _check(lib().rt_camera_perspective(C.byref(self.c), _dp(_vec(eye)), _dp(_vec(center)), _dp(_vec(up)), float(fov),
                                            float(aspect), float(focus_distance), float(lens_radius)))
+
+
+def render_sharded(scenes, cam: "Camera", width, height, spp, max_depth, seed=1) -> np.ndarray:
+    """rt_render_sharded: one host thread per committed scene copy, tiles dealt tile_id % len(scenes)"""
+    p = rt_render_params(width, height, spp, max_depth, seed, 0, 1, 0)
+    out = np.zeros((height, width, 3))
+    arr = (_VP * len(scenes))(*[s._h for s in scenes])
+    _check(lib().rt_render_sharded(arr, len(scenes), C.byref(cam.c), C.byref(p), _dp(out)))
+    return out
 
 
 def shard_tile_count(width, height, shard_index, shard_count) -> int:

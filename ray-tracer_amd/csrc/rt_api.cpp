@@ -18,6 +18,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 extern "C" int rt_launch_render(const RtLaunch *L, unsigned features, int lens, int count, int ldsnodes, int blocks,
@@ -644,6 +645,41 @@ int rt_render(rt_scene *s, const rt_camera *cam, const rt_render_params *p, doub
     return RT_OK;
 }
 
+rt_scene *rt_scene_clone(const rt_scene *src, int device) {
+    if (!src) {
+        fail(RT_ERR_INVALID, "null scene");
+        return nullptr;
+    }
+    rt_scene *s = new rt_scene;
+    s->ir = src->ir;
+    if (src->committed && rt_scene_commit(s, device) != RT_OK) { // g_err is set
+        rt_scene_destroy(s);
+        return nullptr;
+    }
+    return s;
+}
+
+int rt_render_sharded(rt_scene *const *scenes, int n, const rt_camera *cam, const rt_render_params *p, double *out_rgb) {
+    if (!scenes || n <= 0 || !cam || !p || !out_rgb) return fail(RT_ERR_INVALID, "null argument or no scenes");
+    for (int i = 0; i < n; ++i)
+        if (int e = check_params(scenes[i], cam, p)) return e;
+    std::vector<int> rc((size_t)n, RT_OK);
+    std::vector<std::string> msg((size_t)n);
+    std::vector<std::thread> workers;
+    for (int i = 0; i < n; ++i)
+        workers.emplace_back([&, i]() {
+            rt_render_params q = *p;
+            q.shard_index = i;
+            q.shard_count = n;
+            rc[(size_t)i] = rt_render(scenes[i], cam, &q, out_rgb, nullptr); // shards own disjoint pixels of out_rgb
+            if (rc[(size_t)i] != RT_OK) msg[(size_t)i] = rt_last_error();   // thread-local text -> carry it over
+        });
+    for (std::thread &t : workers) t.join();
+    for (int i = 0; i < n; ++i)
+        if (rc[(size_t)i] != RT_OK) return fail(rc[(size_t)i], "shard " + std::to_string(i) + ": " + msg[(size_t)i]);
+    return RT_OK;
+}
+
 int rt_unpack_tiles_device(const void *d_gathered, int tiles_per_shard_padded, int shard_count, int width, int height,
                            void *d_image_out, void *stream) {
     if (!d_gathered || !d_image_out || tiles_per_shard_padded <= 0 || shard_count <= 0 || width <= 0 || height <= 0)
@@ -742,6 +778,39 @@ int rt_scene_copy_nodes(const rt_scene *s, double *out, int max_nodes) {
         o[26] = o[27] = 0.0;
     }
     return n;
+}
+
+int rt_scene_hash(const rt_scene *s, uint64_t *out) {
+    if (!s || !out) return fail(RT_ERR_INVALID, "null argument");
+    if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
+    uint64_t h = 0xcbf29ce484222325ull;
+    auto eat = [&](const void *p, size_t n) {
+        const unsigned char *b = (const unsigned char *)p;
+        for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 0x100000001b3ull;
+    };
+    const rt::FlatScene &f = s->flat;
+    eat(f.prim_meta.data(), f.prim_meta.size() * sizeof(RtPrimMeta));
+    eat(f.prim_geo.data(), f.prim_geo.size() * sizeof(RtPrimGeo));
+    eat(f.prim_extra.data(), f.prim_extra.size() * sizeof(RtPrimExtra));
+    eat(f.xforms.data(), f.xforms.size() * sizeof(RtXform));
+    for (const RtMaterial &m : f.materials) { // field by field: the struct has padding
+        eat(&m.kind, sizeof m.kind);
+        eat(&m.tex, sizeof m.tex);
+        eat(&m.solid, sizeof m.solid);
+        eat(&m.param, sizeof m.param);
+        eat(m.rgb, sizeof m.rgb);
+    }
+    for (const RtTexture &t : f.textures) {
+        eat(&t.kind, sizeof t.kind);
+        eat(&t.a, sizeof t.a);
+        eat(&t.b, sizeof t.b);
+        eat(&t.w, sizeof t.w);
+        eat(&t.h, sizeof t.h);
+        eat(t.rgb, sizeof t.rgb);
+    }
+    eat(f.image_blob.data(), f.image_blob.size());
+    *out = h;
+    return RT_OK;
 }
 
 int rt_scene_prim_bounds(const rt_scene *s, int prim, double out[6]) {

@@ -144,10 +144,9 @@ inline int run(const Options &o, const std::vector<SpritePtr> &sprites, const Pe
     }
     std::vector<Vec3> buffer;
     if (o.gpus > 1) {
-        // The reference deals rows to host threads (examples/book-one.rs:56-65); here tiles are dealt to GPUs: every
-        // thread commits its own copy of the scene on "its" device and renders its shard straight into the shared
-        // image (the shards' pixels are disjoint, so there is nothing to merge and no collective).  Devices wrap
-        // around (--gpus 2 on a one-GPU box renders both shards on device 0), the image does not depend on N.
+        // The reference deals rows to host threads (examples/book-one.rs:56-65); here tiles are dealt to GPUs
+        // (rt_render_sharded: a host thread per committed copy of the scene, shards written straight into one image --
+        // their pixels are disjoint, so there is nothing to merge and no collective); the image does not depend on N.
         const int n_dev = rt_device_count();
         if (n_dev < 1) {
             std::fprintf(stderr, "no HIP device\n");
@@ -157,45 +156,51 @@ inline int run(const Options &o, const std::vector<SpritePtr> &sprites, const Pe
             std::fprintf(stderr, "--gpus cannot be combined with --passes / --checkpoint\n");
             return 2;
         }
-        std::vector<double> rgb((size_t)o.width * o.height * 3, 0.0);
-        std::vector<std::exception_ptr> errors((size_t)o.gpus);
-        std::vector<std::thread> threads;
-        for (int r = 0; r < o.gpus; ++r)
-            threads.emplace_back([&, r]() {
-                try {
-                    auto w = r == 0 ? world : BoundingVolumeHierarchyNode::make(sprites, (o.device + r) % n_dev);
-                    render_shard(*w, camera, o.width, o.height, o.spp, o.depth, o.seed, r, o.gpus, rgb.data());
-                } catch (...) {
-                    errors[(size_t)r] = std::current_exception();
-                }
-            });
-        for (std::thread &t : threads) t.join();
-        for (const std::exception_ptr &e : errors)
-            if (e) std::rethrow_exception(e);
-        buffer.resize((size_t)o.width * o.height);
-        for (size_t i = 0; i < buffer.size(); ++i) buffer[i] = Vec3(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]);
+        // one committed copy per GPU; devices wrap around (--gpus 2 on a one-GPU box renders both shards on device 0)
+        std::vector<BoundingVolumeHierarchyNode> worlds;
+        worlds.push_back(*world);
+        for (int r = 1; r < o.gpus; ++r) worlds.push_back(world->clone((o.device + r) % n_dev));
+        buffer = render_sharded(worlds, camera, o.width, o.height, o.spp, o.depth, o.seed);
     } else if (o.passes <= 1 && o.checkpoint.empty()) {
         buffer = render(*world, camera, o.width, o.height, o.spp, o.depth, o.seed);
     } else {
         // progressive: the reference's only progress report is main.rs printing finished rows to stderr
         // (examples/main.rs:123-125) and it cannot resume; here every pass can be checkpointed
+        // checkpoint = header + raw sums.  The header names the render AND the scene (a resume with another --scene-seed, or
+        // another driver at the same size, must not add samples of a different picture); the file is replaced atomically
+        // (tmp + rename) and a file that does not match or is damaged is refused, never overwritten.
         struct Header {
-            uint64_t magic, width, height, spp, depth, seed, s_done;
-        } h{0x3150545252ull, (uint64_t)o.width, (uint64_t)o.height, (uint64_t)o.spp, (uint64_t)o.depth, o.seed, 0};
+            uint64_t magic, version, width, height, spp, depth, seed, scene_seed, scene_hash, camera_hash, s_done;
+        } h{0x3250545252ull, 2, (uint64_t)o.width, (uint64_t)o.height, (uint64_t)o.spp, (uint64_t)o.depth, o.seed, o.scene_seed,
+            world->hash(), 0, 0};
+        {
+            uint64_t ch = 0xcbf29ce484222325ull;
+            const unsigned char *cb = (const unsigned char *)&camera.c;
+            for (size_t i = 0; i < sizeof camera.c; ++i) ch = (ch ^ cb[i]) * 0x100000001b3ull;
+            h.camera_hash = ch;
+        }
         std::vector<double> sums((size_t)o.width * o.height * 3, 0.0);
         int done = 0;
         if (!o.checkpoint.empty()) {
             if (FILE *f = std::fopen(o.checkpoint.c_str(), "rb")) {
                 Header g{};
-                if (std::fread(&g, sizeof g, 1, f) == 1 && g.magic == h.magic && g.width == h.width && g.height == h.height &&
-                    g.spp == h.spp && g.depth == h.depth && g.seed == h.seed && g.s_done <= h.spp &&
-                    std::fread(sums.data(), sizeof(double), sums.size(), f) == sums.size()) {
-                    done = (int)g.s_done;
-                    std::fprintf(stderr, "resuming %s at %d / %d spp\n", o.checkpoint.c_str(), done, o.spp);
-                } else {
-                    std::fill(sums.begin(), sums.end(), 0.0);
-                }
+                const bool header_ok = std::fread(&g, sizeof g, 1, f) == 1;
+                const bool same = header_ok && g.magic == h.magic && g.version == h.version && g.width == h.width && g.height == h.height &&
+                                  g.spp == h.spp && g.depth == h.depth && g.seed == h.seed && g.scene_seed == h.scene_seed &&
+                                  g.scene_hash == h.scene_hash && g.camera_hash == h.camera_hash && g.s_done <= h.spp;
+                const bool whole = same && std::fread(sums.data(), sizeof(double), sums.size(), f) == sums.size();
                 std::fclose(f);
+                if (!same) {
+                    std::fprintf(stderr, "checkpoint %s belongs to another render (size, spp, depth, seed, scene or camera differ) -- "
+                                         "not touching it; remove it or pass another --checkpoint\n", o.checkpoint.c_str());
+                    return 3;
+                }
+                if (!whole) {
+                    std::fprintf(stderr, "checkpoint %s is truncated -- not touching it\n", o.checkpoint.c_str());
+                    return 3;
+                }
+                done = (int)g.s_done;
+                std::fprintf(stderr, "resuming %s at %d / %d spp\n", o.checkpoint.c_str(), done, o.spp);
             }
         }
         const int passes = o.passes < 1 ? 1 : o.passes;
@@ -206,11 +211,19 @@ inline int run(const Options &o, const std::vector<SpritePtr> &sprites, const Pe
             done = end;
             std::fprintf(stderr, "%d / %d spp\n", done, o.spp);
             if (!o.checkpoint.empty()) {
-                if (FILE *f = std::fopen(o.checkpoint.c_str(), "wb")) {
-                    h.s_done = (uint64_t)done;
-                    std::fwrite(&h, sizeof h, 1, f);
-                    std::fwrite(sums.data(), sizeof(double), sums.size(), f);
-                    std::fclose(f);
+                const std::string tmp = o.checkpoint + ".tmp";
+                FILE *f = std::fopen(tmp.c_str(), "wb");
+                h.s_done = (uint64_t)done;
+                bool ok = f != nullptr;
+                ok = ok && std::fwrite(&h, sizeof h, 1, f) == 1;
+                ok = ok && std::fwrite(sums.data(), sizeof(double), sums.size(), f) == sums.size();
+                ok = ok && std::fflush(f) == 0;
+                if (f) ok = (std::fclose(f) == 0) && ok;
+                ok = ok && std::rename(tmp.c_str(), o.checkpoint.c_str()) == 0;
+                if (!ok) {
+                    std::fprintf(stderr, "cannot write checkpoint %s (the previous one, if any, is intact)\n", o.checkpoint.c_str());
+                    std::remove(tmp.c_str());
+                    return 3;
                 }
             }
         }

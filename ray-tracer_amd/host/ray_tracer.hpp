@@ -7,6 +7,7 @@
 //   SolidColor / CheckerTexture / ImageTexture                   src/material.rs:196-271
 //   Lambertian / Metal / Dielectric / DiffuseLight / Isotropic   src/material.rs:24-326
 //   Sphere / Rectangle / Cube / ConstantMedium                   src/geometry.rs, src/volume.rs
+//   TransformedGeometry, NodeGeometry (a node as a geometry)     src/geometry.rs:185-246, src/sprite.rs:87-93
 //   Sprite::builder().geometry().material().transform().build() src/sprite.rs:22-72
 //   BoundingVolumeHierarchyNode::make(objects) -> optional       src/optimize.rs:366 (None on empty input)
 //   PerspectiveCamera(eye, center, up, fov, aspect, focus, lens) src/camera.rs:25-33
@@ -201,6 +202,16 @@ struct ConstantMedium : Geometry {
     }
 };
 
+// TransformedGeometry::new(geometry, M) (src/geometry.rs:185-246)
+struct TransformedGeometry : Geometry {
+    GeometryPtr geometry;
+    Mat4 transform;
+    TransformedGeometry(GeometryPtr g, const Mat4 &m) : geometry(std::move(g)), transform(m) {}
+    int record(rt_scene *s, std::map<const void *, int> &seen) const override {
+        return check(rt_add_geometry_transformed(s, intern(s, seen, geometry.get()), transform.a.data()));
+    }
+};
+
 // ---- Sprite + builder (src/sprite.rs:22-72) ----
 struct Sprite {
     GeometryPtr geometry_; // Option<Arc<T>>
@@ -208,6 +219,24 @@ struct Sprite {
     Mat4 transform_ = Mat4::identity();
     struct Builder;
     static Builder builder();
+    // records geometry, material and the sprite itself; returns the sprite id
+    int record(rt_scene *s, std::map<const void *, int> &seen) const {
+        int g = geometry_ ? intern(s, seen, geometry_.get()) : -1;
+        int m = material_ ? intern(s, seen, material_.get()) : -1;
+        return check(rt_add_sprite(s, g, m, transform_.a.data()));
+    }
+};
+// BoundingVolumeHierarchyNode::new(vec![sprites...]) used as the GEOMETRY of a sprite -- instancing
+// (src/sprite.rs:87-93 with T = BoundingVolumeHierarchyNode, examples/cornell-box.rs:85-101).  Every sprite that carries
+// the same NodeGeometry is one more instance of it.
+struct NodeGeometry : Geometry {
+    std::vector<std::shared_ptr<Sprite>> children;
+    explicit NodeGeometry(std::vector<std::shared_ptr<Sprite>> c) : children(std::move(c)) {}
+    int record(rt_scene *s, std::map<const void *, int> &seen) const override {
+        std::vector<int> ids;
+        for (const auto &c : children) ids.push_back(c->record(s, seen));
+        return check(rt_add_geometry_bvh(s, ids.data(), (int)ids.size()));
+    }
 };
 struct Sprite::Builder {
     Sprite sprite;
@@ -247,17 +276,26 @@ class BoundingVolumeHierarchyNode {
         BoundingVolumeHierarchyNode w;
         w.scene_.reset(rt_scene_create(), rt_scene_destroy);
         std::map<const void *, int> seen;
-        for (const SpritePtr &sp : objects) {
-            int g = sp->geometry_ ? intern(w.scene_.get(), seen, sp->geometry_.get()) : -1;
-            int m = sp->material_ ? intern(w.scene_.get(), seen, sp->material_.get()) : -1;
-            check(rt_add_sprite(w.scene_.get(), g, m, sp->transform_.a.data()));
-        }
+        for (const SpritePtr &sp : objects) sp->record(w.scene_.get(), seen);
         int rc = rt_scene_commit(w.scene_.get(), device);
         if (rc == RT_ERR_EMPTY) return std::nullopt;
         check(rc);
         return w;
     }
     rt_scene *raw() const { return scene_.get(); }
+    // a second committed copy on another device (rt_scene_clone): the Arc<world> every worker thread holds upstream
+    BoundingVolumeHierarchyNode clone(int device) const {
+        BoundingVolumeHierarchyNode w;
+        rt_scene *c = rt_scene_clone(scene_.get(), device);
+        if (!c) throw Error(RT_ERR_DEVICE, rt_last_error());
+        w.scene_.reset(c, rt_scene_destroy);
+        return w;
+    }
+    uint64_t hash() const {
+        uint64_t h = 0;
+        check(rt_scene_hash(scene_.get(), &h));
+        return h;
+    }
     rt_scene_info info() const {
         rt_scene_info i;
         check(rt_scene_get_info(scene_.get(), &i));
@@ -284,6 +322,19 @@ inline void render_shard(const BoundingVolumeHierarchyNode &world, const Perspec
                          int subPixelSampleCount, int maxDepth, uint64_t seed, int shard_index, int shard_count, double *rgb) {
     rt_render_params p{width, height, subPixelSampleCount, maxDepth, seed, shard_index, shard_count, 0u};
     check(rt_render(world.raw(), &camera.c, &p, rgb, nullptr));
+}
+// The reference's thread fan-out (examples/book-one.rs:52-88) across GPUs: one committed copy of the world per device,
+// tiles dealt tile_id % worlds.size(), one host thread per copy inside the library (rt_render_sharded); bit-identical to render()
+inline std::vector<Vec3> render_sharded(const std::vector<BoundingVolumeHierarchyNode> &worlds, const PerspectiveCamera &camera, int width,
+                                        int height, int subPixelSampleCount, int maxDepth, uint64_t seed) {
+    std::vector<double> rgb((size_t)width * height * 3, 0.0);
+    std::vector<rt_scene *> raw;
+    for (const BoundingVolumeHierarchyNode &w : worlds) raw.push_back(w.raw());
+    rt_render_params p{width, height, subPixelSampleCount, maxDepth, seed, 0, 1, 0u};
+    check(rt_render_sharded(raw.data(), (int)raw.size(), &camera.c, &p, rgb.data()));
+    std::vector<Vec3> out((size_t)width * height);
+    for (size_t i = 0; i < out.size(); ++i) out[i] = Vec3(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]);
+    return out;
 }
 // Progressive form of render(): continues the raw per-pixel sums (width*height*3 doubles, y up) with samples
 // [s_begin, s_end) of the subPixelSampleCount-sample render; divide by subPixelSampleCount after the last

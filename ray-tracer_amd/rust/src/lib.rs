@@ -46,6 +46,32 @@ impl Vec3 {
 /// column-major 4x4, same layout as the reference's `Mat4` (src/mat4.rs:5-17)
 pub type Mat4 = [f64; 16];
 
+/// Mat4::translation / rotation / multiplied / inversed of src/mat4.rs, evaluated by the library (same rounding as the
+/// matrices the kernels use)
+pub fn mat4_translation(t: Vec3) -> Mat4 {
+    let mut m = [0.0; 16];
+    unsafe { ffi::rt_mat4_translation(t.arr().as_ptr(), m.as_mut_ptr()) };
+    m
+}
+pub fn mat4_rotation(radians: f64, axis: Vec3) -> Mat4 {
+    let mut m = [0.0; 16];
+    unsafe { ffi::rt_mat4_rotation(radians, axis.arr().as_ptr(), m.as_mut_ptr()) };
+    m
+}
+pub fn mat4_multiplied(a: &Mat4, b: &Mat4) -> Mat4 {
+    let mut m = [0.0; 16];
+    unsafe { ffi::rt_mat4_multiplied(a.as_ptr(), b.as_ptr(), m.as_mut_ptr()) };
+    m
+}
+pub fn mat4_inversed(a: &Mat4) -> Option<Mat4> {
+    let mut m = [0.0; 16];
+    if unsafe { ffi::rt_mat4_inversed(a.as_ptr(), m.as_mut_ptr()) } == ffi::RT_OK {
+        Some(m)
+    } else {
+        None
+    }
+}
+
 pub enum Texture {
     SolidColor(Vec3),
     Checker(Arc<Texture>, Arc<Texture>),
@@ -71,7 +97,12 @@ pub enum Geometry {
     Rectangle(f64, f64),
     /// BoundingVolumeHierarchyNode::new(Cube::new(w, h, d)) as the examples wrap it
     Cube(f64, f64, f64),
+    /// ConstantMedium::new(boundary, density): any boundary but another medium (src/volume.rs:18-44)
     ConstantMedium(Arc<Geometry>, f64),
+    /// TransformedGeometry::new(geometry, M) (src/geometry.rs:185-246)
+    Transformed(Arc<Geometry>, Mat4),
+    /// BoundingVolumeHierarchyNode::new(sprites) used as a sprite's geometry: instancing (src/sprite.rs:87-93)
+    Node(Vec<Sprite>),
 }
 
 pub struct Sprite {
@@ -182,6 +213,17 @@ impl Recorder {
         self.seen.insert(key, id);
         Ok(id)
     }
+    fn sprite(&mut self, s: &Sprite) -> Result<i32, Error> {
+        let g = match &s.geometry {
+            Some(g) => self.geometry(g)?,
+            None => -1,
+        };
+        let m = match &s.material {
+            Some(m) => self.material(m)?,
+            None => -1,
+        };
+        check(unsafe { ffi::rt_add_sprite(self.raw, g, m, s.transform.as_ptr()) })
+    }
     fn geometry(&mut self, g: &Arc<Geometry>) -> Result<i32, Error> {
         let key = Arc::as_ptr(g) as usize;
         if let Some(id) = self.seen.get(&key) {
@@ -194,6 +236,17 @@ impl Recorder {
             Geometry::ConstantMedium(b, density) => {
                 let b = self.geometry(b)?;
                 check(unsafe { ffi::rt_add_geometry_constant_medium(self.raw, b, *density) })?
+            }
+            Geometry::Transformed(inner, m) => {
+                let inner = self.geometry(inner)?;
+                check(unsafe { ffi::rt_add_geometry_transformed(self.raw, inner, m.as_ptr()) })?
+            }
+            Geometry::Node(children) => {
+                let mut ids = Vec::with_capacity(children.len());
+                for c in children {
+                    ids.push(self.sprite(c)?);
+                }
+                check(unsafe { ffi::rt_add_geometry_bvh(self.raw, ids.as_ptr(), ids.len() as i32) })?
             }
         };
         self.seen.insert(key, id);
@@ -209,15 +262,7 @@ impl BoundingVolumeHierarchyNode {
         let world = Self { raw }; // dropped (destroyed) on every early return
         let mut rec = Recorder { raw, seen: HashMap::new() };
         for s in objects {
-            let g = match &s.geometry {
-                Some(g) => rec.geometry(g)?,
-                None => -1,
-            };
-            let m = match &s.material {
-                Some(m) => rec.material(m)?,
-                None => -1,
-            };
-            check(unsafe { ffi::rt_add_sprite(raw, g, m, s.transform.as_ptr()) })?;
+            rec.sprite(s)?;
         }
         let rc = unsafe { ffi::rt_scene_commit(raw, device) };
         if rc == ffi::RT_ERR_EMPTY {
@@ -250,6 +295,82 @@ impl BoundingVolumeHierarchyNode {
         };
         check(unsafe { ffi::rt_render(self.raw, &camera.raw, &p, rgb.as_mut_ptr(), std::ptr::null_mut()) })?;
         Ok(rgb.chunks(3).map(|c| Vec3::new(c[0], c[1], c[2])).collect())
+    }
+}
+impl BoundingVolumeHierarchyNode {
+    /// A second committed copy on another device: what `Arc::clone(&world)` hands every worker thread upstream
+    /// (examples/book-one.rs:57-59), one per GPU here.
+    pub fn clone_to(&self, device: i32) -> Result<Self, Error> {
+        let raw = unsafe { ffi::rt_scene_clone(self.raw, device) };
+        if raw.is_null() {
+            check(ffi::RT_ERR_DEVICE)?;
+        }
+        Ok(Self { raw })
+    }
+
+    /// The thread fan-out + mpsc gather of examples/book-one.rs:52-88 across GPUs: `worlds[i]` is a committed copy on
+    /// its own device, tiles are dealt `tile_id % worlds.len()`, one host thread per copy inside the library.
+    /// Bit-identical to `render` for any number of copies.
+    pub fn render_sharded(
+        worlds: &[&BoundingVolumeHierarchyNode],
+        camera: &PerspectiveCamera,
+        width: usize,
+        height: usize,
+        subPixelSampleCount: usize,
+        maxDepth: usize,
+        seed: u64,
+    ) -> Result<Vec<Vec3>, Error> {
+        let mut rgb = vec![0.0f64; width * height * 3];
+        let raws: Vec<*mut ffi::rt_scene> = worlds.iter().map(|w| w.raw).collect();
+        let p = ffi::rt_render_params {
+            width: width as i32,
+            height: height as i32,
+            spp: subPixelSampleCount as i32,
+            max_depth: maxDepth as i32,
+            seed,
+            shard_index: 0,
+            shard_count: 1,
+            flags: 0,
+        };
+        check(unsafe { ffi::rt_render_sharded(raws.as_ptr(), raws.len() as i32, &camera.raw, &p, rgb.as_mut_ptr()) })?;
+        Ok(rgb.chunks(3).map(|c| Vec3::new(c[0], c[1], c[2])).collect())
+    }
+
+    /// Progressive form of `render`: continues the raw per-pixel sums (`width * height * 3`, y up) with samples
+    /// `[s_begin, s_end)` of the `subPixelSampleCount`-sample render; divide by `subPixelSampleCount` after the last range.
+    /// Save `sums` and `s_end` (and `scene_hash()`) to checkpoint; the result is bit-identical to one `render` call.
+    pub fn render_progressive(
+        &self,
+        camera: &PerspectiveCamera,
+        width: usize,
+        height: usize,
+        subPixelSampleCount: usize,
+        maxDepth: usize,
+        seed: u64,
+        s_begin: usize,
+        s_end: usize,
+        sums: &mut [f64],
+    ) -> Result<(), Error> {
+        assert_eq!(sums.len(), width * height * 3);
+        let p = ffi::rt_render_params {
+            width: width as i32,
+            height: height as i32,
+            spp: subPixelSampleCount as i32,
+            max_depth: maxDepth as i32,
+            seed,
+            shard_index: 0,
+            shard_count: 1,
+            flags: 0,
+        };
+        check(unsafe { ffi::rt_render_progressive(self.raw, &camera.raw, &p, s_begin as i32, s_end as i32, sums.as_mut_ptr()) })?;
+        Ok(())
+    }
+
+    /// identifies the committed scene (checkpoints)
+    pub fn scene_hash(&self) -> Result<u64, Error> {
+        let mut h = 0u64;
+        check(unsafe { ffi::rt_scene_hash(self.raw, &mut h) })?;
+        Ok(h)
     }
 }
 impl Drop for BoundingVolumeHierarchyNode {

@@ -116,8 +116,8 @@ def test_cpp_driver_progressive_and_resume(binaries, gpu_device, tmp_path):
     # truncate the checkpoint's progress to 4 spp worth of sums by re-running passes from a saved early state
     import struct
     raw = ck.read_bytes()
-    hdr = list(struct.unpack("<7Q", raw[:56]))
-    assert hdr[1:6] == [64, 40, 12, 50, 9] and hdr[6] == 12
+    hdr = list(struct.unpack("<11Q", raw[:88]))
+    assert hdr[1:8] == [2, 64, 40, 12, 50, 9, 3] and hdr[10] == 12
     # build a genuine 4-spp checkpoint with the API and let the driver resume it
     import importlib
     import numpy as np
@@ -127,13 +127,30 @@ def test_cpp_driver_progressive_and_resume(binaries, gpu_device, tmp_path):
     sc, cam = scenes.build_product(scenes.book_one(3, 64 / 40), device=gpu_device)
     sums = np.zeros((40, 64, 3))
     sc.render_progressive(cam, 64, 40, 12, 50, 9, 0, 4, sums)
-    hdr[6] = 4
-    ck.write_bytes(struct.pack("<7Q", *hdr) + sums.tobytes())
+    assert hdr[8] == sc.scene_hash()  # the header names the scene the sums belong to
+    hdr[10] = 4
+    ck.write_bytes(struct.pack("<11Q", *hdr) + sums.tobytes())
     res = tmp_path / "resumed.ppm"
     r = subprocess.run([str(binaries / "book_one"), *common, "--passes", "3", "--checkpoint", str(ck), "--out", str(res)],
                        check=True, capture_output=True, text=True)
     assert "resuming" in r.stderr and "at 4 / 12 spp" in r.stderr
     assert res.read_bytes() == one.read_bytes()
+    assert not (tmp_path / "ck.bin.tmp").exists()  # replaced atomically
+    # a checkpoint of ANOTHER scene (other --scene-seed) or another driver is refused and left alone
+    before = ck.read_bytes()
+    other = [a if a != "3" else "4" for a in common]
+    assert "--scene-seed" in other and other[other.index("--scene-seed") + 1] == "4"
+    r = subprocess.run([str(binaries / "book_one"), *other, "--passes", "3", "--checkpoint", str(ck), "--out", str(res)],
+                       capture_output=True, text=True)
+    assert r.returncode == 3 and "belongs to another render" in r.stderr and ck.read_bytes() == before
+    r = subprocess.run([str(binaries / "cornell_box"), *common, "--passes", "3", "--checkpoint", str(ck), "--out", str(res)],
+                       capture_output=True, text=True)
+    assert r.returncode == 3 and ck.read_bytes() == before
+    # a truncated file is refused as well (never silently restarted from zero)
+    ck.write_bytes(before[:len(before) // 2])
+    r = subprocess.run([str(binaries / "book_one"), *common, "--passes", "3", "--checkpoint", str(ck), "--out", str(res)],
+                       capture_output=True, text=True)
+    assert r.returncode == 3 and "truncated" in r.stderr and ck.read_bytes() == before[:len(before) // 2]
 
 
 @pytest.mark.gpu

@@ -275,6 +275,20 @@ def test_config5_one_full_shard_3840x2160x2000(rt, scenes, oracle, gpu_device):
         checked += 1
 
 
+def test_render_sharded_over_scene_clones(rt, scenes, gpu_device):
+    """rt_scene_clone + rt_render_sharded: the drivers' thread fan-out (examples/book-one.rs:52-88) inside the library --
+    one host thread per committed copy, tiles dealt tile_id % n; clones wrap around on this one-GPU box"""
+    W, H, spp, depth = 100, 60, 4, 50
+    sc, cam = scenes.build_product(scenes.book_one(2, W / H), device=gpu_device)
+    whole = sc.render(cam, W, H, spp, depth, seed=3)
+    for n in (1, 2, 3):
+        copies = [sc] + [sc.clone(gpu_device) for _ in range(n - 1)]
+        assert copies[-1].scene_hash() == sc.scene_hash()
+        assert np.array_equal(rt.render_sharded(copies, cam, W, H, spp, depth, seed=3), whole)
+    with pytest.raises(rt.RtError):
+        sc.clone(99)  # no such device
+
+
 def test_instanced_scene_matches_oracle(rt, scenes, oracle, gpu_device):
     """instanced nodes (up to four transform levels), media over a cube / a node of spheres / behind a TransformedGeometry,
     instanced media keyed per instance: the kernel family with medium_general_hit against the oracle's recursive walk"""

@@ -22,6 +22,25 @@ def test_abi_exports_every_declared_symbol(rt):
     assert declared == set(rt.ABI), "python binding table and header disagree"
 
 
+def test_rust_ffi_declares_every_entry_point():
+    """ray-tracer_amd/rust/src/ffi.rs (uncompilable here: no Rust toolchain) against include/rt_mi355x.h, mechanically:
+    the same set of functions, and the same field counts for the structs that cross the boundary"""
+    import re
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    header = re.sub(r"/\*.*?\*/", "", (root / "include" / "rt_mi355x.h").read_text(), flags=re.S)
+    declared = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", header))
+    ffi = (root / "ray-tracer_amd" / "rust" / "src" / "ffi.rs").read_text()
+    bound = set(re.findall(r"pub fn (rt_[a-z0-9_]+)\s*\(", ffi))
+    assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
+    for struct in ("rt_camera", "rt_render_params", "rt_counters", "rt_launch_config", "rt_scene_info"):
+        c_body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), header, flags=re.S).group(1)
+        c_fields = sum(len(decl.split(",")) for decl in re.findall(r"[a-z_0-9 ]+?\s+([a-z_0-9, \[\]]+);", c_body))
+        r_body = re.search(r"pub struct %s \{(.*?)\n\}" % struct, ffi, flags=re.S).group(1)
+        r_fields = len(re.findall(r"pub [a-z_0-9]+:", r_body))
+        assert c_fields == r_fields, (struct, c_fields, r_fields)
+
+
 def test_no_cpu_rendering_path(rt, scenes):
     """Without a HIP device the product must fail loudly, never fall back."""
     sc, cam = scenes.build_product(scenes.book_one(1, 1.5), device=-1)
