@@ -268,6 +268,7 @@ int rt_probe_device_math(int device, const double *a, const double *b, int n, do
 #define RT_FEAT_MEDIUM 4u     /* ConstantMedium */
 #define RT_FEAT_TEXTURED 8u   /* checker / image textures (uv needed) */
 #define RT_FEAT_LENS 16u
+#define RT_FEAT_WIDE 64u           /* more than 32767 prims or nodes: 32-bit node references, two LDS words per stack entry */
 #define RT_FEAT_MEDIUM_GENERAL 32u /* a ConstantMedium whose boundary is not a plain sphere under a pure translation */
 
 #ifdef __cplusplus

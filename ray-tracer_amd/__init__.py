@@ -26,7 +26,7 @@ LIB_PATH = Path(os.environ.get("RT_MI355X_LIB") or (_HERE / "lib" / "librt_mi355
 
 RT_TILE = 8
 RT_FLAG_COUNTERS = 1
-RT_FEAT_SPHERE_T, RT_FEAT_GENERAL, RT_FEAT_MEDIUM, RT_FEAT_TEXTURED, RT_FEAT_LENS, RT_FEAT_MEDIUM_GENERAL = 1, 2, 4, 8, 16, 32
+RT_FEAT_SPHERE_T, RT_FEAT_GENERAL, RT_FEAT_MEDIUM, RT_FEAT_TEXTURED, RT_FEAT_LENS, RT_FEAT_MEDIUM_GENERAL, RT_FEAT_WIDE = 1, 2, 4, 8, 16, 32, 64
 
 
 class RtError(RuntimeError):

@@ -29,6 +29,7 @@ extern "C" int rt_kernel_block_size(unsigned features);
 extern "C" int rt_kernel_waves_per_simd(unsigned features);
 extern "C" unsigned rt_swap_lds_bytes(unsigned cap);
 extern "C" unsigned rt_swap_cap_max(void);
+extern "C" unsigned rt_stack_entry_bytes(int wide);
 extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int ldsnodes, unsigned lds_bytes, int *blocks_per_cu,
                                     int *n_cu);
 extern "C" int rt_launch_unpack(const double *gathered, int tiles_per_shard, int shard_count, int width, int height,
@@ -314,6 +315,7 @@ static unsigned kernel_features(const rt_scene *s) {
     if (s->flat.feature_mask & RT_FEAT_MEDIUM) f |= 2u;
     if (s->flat.feature_mask & RT_FEAT_TEXTURED) f |= 4u;
     if (s->flat.feature_mask & RT_FEAT_MEDIUM_GENERAL) f |= 8u;
+    if (s->flat.wide) f |= 1u; // 32-bit references exist in the general kernel families only
     return f;
 }
 
@@ -379,7 +381,8 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     // dynamic LDS: the traversal stack, plus a copy of the node array when three workgroups
     // of it still fit the CU's 160 KiB (book-one: 31 KB of nodes + 12 KB of stack)
     const unsigned block = (unsigned)rt_kernel_block_size(feat);
-    const unsigned stack_bytes = (unsigned)L.stack_entries * block * 4u;
+    const int wide = s->flat.wide ? 1 : 0;
+    const unsigned stack_bytes = (unsigned)L.stack_entries * block * rt_stack_entry_bytes(wide);
     const unsigned node_bytes = (unsigned)(s->flat.nodes.size() * sizeof(RtNode));
     const char *no_lds = std::getenv("RT_NO_LDS_NODES");
     // swap-at-shade queues (rt_kernels.hip); RT_SWAP=0 selects the kernels without them (A/B runs)
@@ -396,13 +399,13 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
         if (other + hdr + 16u * per_entry > lds_share) return 16u; // does not fit anyway: fewer groups will be resident
         return std::min(rt_swap_cap_max(), (lds_share - other - hdr) / per_entry);
     };
-    const int ldsnodes = node_bytes > 0 && stack_bytes + node_bytes + (swap ? rt_swap_lds_bytes(block >= 512u ? 0u : 32u) : 0u) <= lds_share &&
+    const int ldsnodes = !wide && node_bytes > 0 && stack_bytes + node_bytes + (swap ? rt_swap_lds_bytes(block >= 512u ? 0u : 32u) : 0u) <= lds_share &&
                          !(no_lds && *no_lds == '1');
     const unsigned swap_cap = swap_cap_that_fits(stack_bytes + (ldsnodes ? node_bytes : 0u));
     const unsigned swap_bytes = swap ? rt_swap_lds_bytes(swap_cap) : 0u;
     L.swap_cap = (int)swap_cap;
     const unsigned lds_bytes = stack_bytes + (ldsnodes ? node_bytes : 0u) + swap_bytes;
-    const int lds_mode = (ldsnodes ? 1 : 0) | (swap ? 2 : 0);
+    const int lds_mode = (ldsnodes ? 1 : 0) | (swap ? 2 : 0) | (wide ? 4 : 0);
     int per_cu = 0, n_cu = 0, rc = 0;
     const unsigned occ_key = feat | (lens ? 8u : 0u) | (count ? 16u : 0u) | ((unsigned)lds_mode << 5);
     if (s->occ_key == occ_key && s->occ_lds == lds_bytes) {

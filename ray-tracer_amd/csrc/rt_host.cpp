@@ -645,8 +645,8 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
         if (err) *err = "empty scene: BoundingVolumeHierarchyNode::new(vec![]) is None (src/optimize.rs:367-370)";
         return RT_ERR_EMPTY;
     }
-    if (leaves.size() > RT_REF_MAX) {
-        if (err) *err = "more than 32767 primitives: outside the 16-bit node references of this build";
+    if (leaves.size() > (size_t)RT_REF_MAX_W) {
+        if (err) *err = "more than 2^31 primitives";
         return RT_ERR_UNSUPPORTED;
     }
 
@@ -724,11 +724,13 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
     // BVH over the non-hoisted leaves
     if (fs.n_hoisted < fs.n_leaf_prims) {
         const int32_t r = build_bvh(fs.prim_bounds, fs.n_hoisted, fs.n_leaf_prims, &fs.host_nodes, &fs.max_depth);
-        if (fs.host_nodes.size() > RT_REF_MAX) {
-            if (err) *err = "BVH has more than 32767 nodes: outside the 16-bit node references of this build";
-            return RT_ERR_UNSUPPORTED;
-        }
-        auto ref16 = [](int32_t c) { return c >= 0 ? (uint32_t)c : (RT_REF_LEAF | (uint32_t)(~c)); };
+        // up to 32767 prims and nodes: 16-bit references (one LDS word per stack entry); beyond: 32-bit ones
+        fs.wide = (size_t)fs.n_leaf_prims > RT_REF_MAX || fs.host_nodes.size() > RT_REF_MAX;
+        if (fs.wide) fs.feature_mask |= RT_FEAT_WIDE;
+        const bool wide = fs.wide;
+        auto ref16 = [wide](int32_t c) {
+            return c >= 0 ? (uint32_t)c : ((wide ? RT_REF_LEAF_W : RT_REF_LEAF) | (uint32_t)(~c));
+        };
         fs.root = ref16(r);
         for (const HostNode &h : fs.host_nodes) {
             RtNode n{};
@@ -746,7 +748,7 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
             fs.nodes.push_back(n);
         }
     } else {
-        fs.root = RT_CUR_DONE;
+        fs.root = RT_CUR_DONE; // every prim is hoisted (only possible in the 16-bit form)
         fs.max_depth = 0;
     }
     // the material's kind rides in the prim's meta word (RtPrimMeta::kind bits 8-15)

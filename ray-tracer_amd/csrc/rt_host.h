@@ -71,7 +71,8 @@ struct FlatScene {
     std::vector<RtMaterial> materials;
     std::vector<RtTexture> textures;
     std::vector<uint8_t> image_blob;
-    uint32_t root = RT_CUR_DONE; // 16-bit reference (RT_REF_*) or RT_CUR_DONE if the BVH is empty
+    uint32_t root = RT_CUR_DONE; // reference (RT_REF_*) or RT_CUR_DONE if the BVH is empty
+    bool wide = false;           // 32-bit references (more than 32767 prims or nodes)
     int n_leaf_prims = 0;
     int max_depth = 0;
     unsigned feature_mask = 0;

@@ -134,17 +134,49 @@
 
 namespace {
 
+// 16-bit references: one LDS word per entry = tnear truncated to its upper 16 bits | reference
 template <int BLOCK>
 struct LdsStack {
+    typedef RtRef16 Ref;
+    static constexpr unsigned kEntryBytes = 4;
     uint32_t *base; // &stack[threadIdx.x]
-    __device__ __forceinline__ void push(int32_t &sp, uint32_t v) {
-        base[sp * BLOCK] = v;
+    __device__ __forceinline__ void set(unsigned char *lds) { base = reinterpret_cast<uint32_t *>(lds) + threadIdx.x; }
+    __device__ __forceinline__ void push(int32_t &sp, float tnear, uint32_t ref) {
+        base[sp * BLOCK] = (__float_as_uint(tnear) & 0xFFFF0000u) | ref;
         ++sp;
     }
-    __device__ __forceinline__ uint32_t pop(int32_t &sp) {
+    __device__ __forceinline__ void pop(int32_t &sp, float *tnear, uint32_t *ref) {
         --sp;
-        return base[sp * BLOCK];
+        const uint32_t e = base[sp * BLOCK];
+        *tnear = __uint_as_float(e & 0xFFFF0000u);
+        *ref = e & 0xFFFFu;
     }
+};
+// 32-bit references (scenes of more than 32767 prims or nodes): two words per entry, [depth][thread] of 8 bytes
+template <int BLOCK>
+struct LdsStackWide {
+    typedef RtRef32 Ref;
+    static constexpr unsigned kEntryBytes = 8;
+    uint2 *base;
+    __device__ __forceinline__ void set(unsigned char *lds) { base = reinterpret_cast<uint2 *>(lds) + threadIdx.x; }
+    __device__ __forceinline__ void push(int32_t &sp, float tnear, uint32_t ref) {
+        base[sp * BLOCK] = make_uint2(__float_as_uint(tnear), ref);
+        ++sp;
+    }
+    __device__ __forceinline__ void pop(int32_t &sp, float *tnear, uint32_t *ref) {
+        --sp;
+        const uint2 e = base[sp * BLOCK];
+        *tnear = __uint_as_float(e.x);
+        *ref = e.y;
+    }
+};
+template <int BLOCK, bool WIDE>
+struct StackOf {
+    typedef LdsStack<BLOCK> type;
+};
+template <int BLOCK>
+struct StackOf<BLOCK, true> {
+    typedef LdsStackWide<BLOCK> type;
 };
 // workgroup size and waves per SIMD of each kernel family
 __host__ __device__ constexpr int block_of(bool general, int medium) {
@@ -154,6 +186,25 @@ __host__ __device__ constexpr int waves_of(bool general, int medium) {
     return general ? (medium >= 2 ? RT_WAVES_PER_EU_GENERAL : (medium == 1 ? RT_WAVES_PER_EU_MEDIUM : RT_WAVES_PER_EU_LEAN)) : RT_WAVES_PER_EU;
 }
 
+// one 32-byte aligned record per sample, two 16-byte stores: whole sectors, no read-modify-write of partially written
+// lines at the memory side.  The records are written once and read once by reduce_kernel, and a lane's record lands
+// 2 KB from its neighbour's (sample-major layout, pixel-major hand-out): the stores are marked non-temporal -- measured
+// WRITE_SIZE per 1200x800x500 launch 20.6 GB with plain stores, 17.0 GB with nt, against 15.36 GB of records; same speed.
+#ifndef RT_NT_STORE
+#define RT_NT_STORE 1
+#endif
+__device__ __forceinline__ void store_sample(double *samples, uint32_t slot, rtl::V3 rad) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    v2d *o = reinterpret_cast<v2d *>(samples + (size_t)slot * 4);
+    const v2d a = {rad.x, rad.y}, b = {rad.z, 0.0};
+    if (RT_NT_STORE) {
+        __builtin_nontemporal_store(a, o);
+        __builtin_nontemporal_store(b, o + 1);
+    } else {
+        o[0] = a;
+        o[1] = b;
+    }
+}
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) { // set bits below this lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -164,25 +215,27 @@ __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__bui
 // in ~1/4 of an L2 hit.
 extern __shared__ __attribute__((aligned(16))) unsigned char rt_lds[];
 
-template <bool GENERAL, int MEDIUM, bool TEXTURED, bool LENS, bool COUNT, bool LDSNODES, bool SWAP>
+template <bool GENERAL, int MEDIUM, bool TEXTURED, bool LENS, bool COUNT, bool LDSNODES, bool SWAP, bool WIDE>
 __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM)) void render_kernel(const RtLaunch L) {
     constexpr int kBlock = block_of(GENERAL, MEDIUM);
+    typedef typename StackOf<kBlock, WIDE>::type Stack;
+    typedef typename Stack::Ref Ref;
     // entries per class queue: the most (<= RT_SWAP_CAP) that leaves the kernel family's full occupancy resident (host)
     // (a compile-time constant for the 512-thread families: the address arithmetic of a run-time capacity costs the
     // book-one kernel 2 %)
     const uint32_t kSwapCap = kBlock >= 512 ? (uint32_t)RT_SWAP_CAP : (uint32_t)L.swap_cap, kSwapClassBytes = RT_SWAP_ENTRY_BYTES * kSwapCap;
-    uint32_t *stack_mem = reinterpret_cast<uint32_t *>(rt_lds);
-    LdsStack<kBlock> st;
-    st.base = stack_mem + threadIdx.x;
+    Stack st;
+    st.set(rt_lds);
+    constexpr size_t kStackEntry = Stack::kEntryBytes;
     const RtNode *nodes = L.nodes;
     const unsigned node_lds_bytes = LDSNODES ? (unsigned)L.n_nodes * (unsigned)sizeof(RtNode) : 0u;
     // swap queues: header {state[3], pad...}: state = entries in the queue | kSwapLock while a wave works on it; then per class RT_SWAP_F64 arrays of CAP doubles and
     // RT_SWAP_F32 arrays of CAP words (field-major: consecutive entries are consecutive addresses)
-    unsigned char *swap_mem = rt_lds + (size_t)L.stack_entries * kBlock * sizeof(uint32_t) + node_lds_bytes;
+    unsigned char *swap_mem = rt_lds + (size_t)L.stack_entries * kBlock * kStackEntry + node_lds_bytes;
     uint32_t *swap_hdr = reinterpret_cast<uint32_t *>(swap_mem);
     if (SWAP && threadIdx.x < RT_SWAP_HDR_BYTES / 4u) swap_hdr[threadIdx.x] = 0u;
     if (LDSNODES) {
-        uint4 *dst = reinterpret_cast<uint4 *>(rt_lds + (size_t)L.stack_entries * kBlock * sizeof(uint32_t));
+        uint4 *dst = reinterpret_cast<uint4 *>(rt_lds + (size_t)L.stack_entries * kBlock * kStackEntry);
         const uint4 *src = reinterpret_cast<const uint4 *>(L.nodes);
         const int n16 = L.n_nodes * (int)(sizeof(RtNode) / 16);
         for (int i = (int)threadIdx.x; i < n16; i += kBlock) dst[i] = src[i];
@@ -192,7 +245,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
 
     rtl::PathState ps;
     rtl::Trav tv;
-    tv.cur = RT_CUR_DONE;
+    tv.cur = Ref::kDone;
     tv.sp = 0;
     tv.best_prim = 0xFFFFFFFFu;
     tv.best_t = 0.0;
@@ -211,9 +264,9 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
     const bool counting_lane = COUNT && (threadIdx.x & 63) == 0;
 
     for (;;) {
-        const bool is_done = tv.cur == RT_CUR_DONE;
-        const bool is_leaf = (tv.cur & (RT_REF_LEAF | RT_CUR_DONE | RT_CUR_DEAD)) == RT_REF_LEAF;
-        const bool is_node = tv.cur < RT_REF_LEAF;
+        const bool is_done = tv.cur == Ref::kDone;
+        const bool is_leaf = tv.cur >= Ref::kLeaf && tv.cur < Ref::kDone;
+        const bool is_node = tv.cur < Ref::kLeaf;
         const unsigned long long mS = __ballot(is_done), mL = __ballot(is_leaf), mN = __ballot(is_node);
         if ((mS | mL | mN) == 0ull) { // every lane is dead
             if (!SWAP) break;
@@ -244,7 +297,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                 // 1. classify.  Paths that end here without a hit record (black background, no material, a light
                 //    of one colour) are settled at once, so their lanes can take a parked path below.
                 uint32_t cls = kNone;
-                if ((is_done && !has_path) || tv.cur == RT_CUR_DEAD) cls = kEmpty;
+                if ((is_done && !has_path) || tv.cur == Ref::kDead) cls = kEmpty;
                 if (is_done && has_path) {
                     uint32_t mat = RT_NO_MATERIAL, kind = RT_MAT_KIND_NONE;
                     if (tv.best_prim != 0xFFFFFFFFu) { // one 8-byte load: the material's kind rides in the meta word
@@ -259,9 +312,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                     } else {
                         rtl::V3 rad = rtl::mk(0.0, 0.0, 0.0);
                         if (kind == RT_MAT_DIFFUSE_LIGHT) rad = ps.T * rtl::ld3(L.materials[mat].rgb); // finish_segment's T * emit
-                        double2 *o = reinterpret_cast<double2 *>(L.samples + (size_t)slot * 4);
-                        o[0] = make_double2(rad.x, rad.y);
-                        o[1] = make_double2(rad.z, 0.0);
+                        store_sample(L.samples, slot, rad);
                         has_path = false;
                         cls = kEmpty;
                         if (COUNT) {
@@ -407,7 +458,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                             ps.k = (int32_t)f32[0 * kSwapCap];
                             tv.best_prim = f32[1 * kSwapCap];
                             slot = f32[2 * kSwapCap];
-                            tv.cur = RT_CUR_DONE;
+                            tv.cur = Ref::kDone;
                             tv.sp = 0;
                             has_path = true;
                             cls = cstar;
@@ -440,9 +491,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                         if (mode_new || cls != cstar) ++w_off;
                     }
                     if (fin) {
-                        double2 *o = reinterpret_cast<double2 *>(L.samples + (size_t)slot * 4);
-                        o[0] = make_double2(rad.x, rad.y);
-                        o[1] = make_double2(rad.z, 0.0);
+                        store_sample(L.samples, slot, rad);
                         has_path = false;
                         if (COUNT) {
                             c_draws += ps.g.draws;
@@ -461,9 +510,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                     if (fin) {
                         // one 32-byte aligned record per sample, two 16-byte stores: whole sectors,
                         // no read-modify-write of partially written lines at the memory side
-                        double2 *o = reinterpret_cast<double2 *>(L.samples + (size_t)slot * 4);
-                        o[0] = make_double2(rad.x, rad.y);
-                        o[1] = make_double2(rad.z, 0.0);
+                        store_sample(L.samples, slot, rad);
                         has_path = false;
                         if (COUNT) {
                             c_draws += ps.g.draws;
@@ -526,7 +573,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                 if (has_path)
                     rtl::begin_segment<GENERAL, MEDIUM, TEXTURED>(L, &ps, tv, st, &c_prims);
                 else // SWAP: an empty lane waits (DONE, no path) for a parked path or the next bulk refill
-                    tv.cur = (!SWAP || queue_empty) ? RT_CUR_DEAD : RT_CUR_DONE;
+                    tv.cur = (!SWAP || queue_empty) ? Ref::kDead : Ref::kDone;
             }
             RT_STAMP(t1);
             t_beg += t1 - t0;
@@ -544,7 +591,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
             // ---------------- node block ----------------
             RT_STAMP(t0);
             for (;;) {
-                const bool at_node = tv.cur < RT_REF_LEAF;
+                const bool at_node = tv.cur < Ref::kLeaf;
                 const int n = __popcll(__ballot(at_node));
                 if (n == 0) break;
                 if (COUNT && counting_lane) {
@@ -661,9 +708,9 @@ __global__ void probe_math_kernel(const double *a, const double *b, int n, doubl
 // ---- dispatch over the template instantiations ----
 typedef void (*KernelFn)(const RtLaunch);
 
-template <bool GENERAL, int MEDIUM, bool TEXTURED, bool SWAP>
+template <bool GENERAL, int MEDIUM, bool TEXTURED, bool SWAP, bool WIDE = false>
 KernelFn pick3(bool lens, bool count, bool ldsnodes) {
-#define RT_PICK(LN, C, LD) return render_kernel<GENERAL, MEDIUM, TEXTURED, LN, C, LD, SWAP>
+#define RT_PICK(LN, C, LD) return render_kernel<GENERAL, MEDIUM, TEXTURED, LN, C, LD && !WIDE, SWAP, WIDE>
     if (lens) {
         if (count) {
             if (ldsnodes) RT_PICK(true, true, true); else RT_PICK(true, true, false);
@@ -679,9 +726,14 @@ KernelFn pick3(bool lens, bool count, bool ldsnodes) {
     }
 #undef RT_PICK
 }
-// lds_mode: bit 0 = node array copied to LDS, bit 1 = swap-at-shade queues
+// lds_mode: bit 0 = node array copied to LDS, bit 1 = swap-at-shade queues, bit 2 = 32-bit references (general families)
 KernelFn pick(unsigned features, bool lens, bool count, int lds_mode) {
-    const bool ldsnodes = (lds_mode & 1) != 0, swap = (lds_mode & 2) != 0;
+    const bool ldsnodes = (lds_mode & 1) != 0, swap = (lds_mode & 2) != 0, wide = (lds_mode & 4) != 0;
+    if (wide) { // more than 32767 prims or nodes: the node array never fits LDS
+        if ((features & ~1u) == 0u) return swap ? pick3<true, 0, false, true, true>(lens, count, false) : pick3<true, 0, false, false, true>(lens, count, false);
+        if (features & 8u) return swap ? pick3<true, 2, true, true, true>(lens, count, false) : pick3<true, 2, true, false, true>(lens, count, false);
+        return swap ? pick3<true, 1, true, true, true>(lens, count, false) : pick3<true, 1, true, false, true>(lens, count, false);
+    }
     // general prims only (matrices, rectangles, cubes: the Cornell box): no medium / texture code in the kernel
     if (features == 1u) return swap ? pick3<true, 0, false, true>(lens, count, ldsnodes) : pick3<true, 0, false, false>(lens, count, ldsnodes);
     // media over a general boundary (bit 8): the kernel with medium_general_hit; else the one with sphere media only
@@ -722,6 +774,7 @@ extern "C" unsigned rt_swap_lds_bytes(unsigned cap) {
     return RT_SWAP_HDR_BYTES + RT_SWAP_CLASSES * RT_SWAP_ENTRY_BYTES * (cap ? cap : (unsigned)RT_SWAP_CAP);
 }
 extern "C" unsigned rt_swap_cap_max(void) { return RT_SWAP_CAP; }
+extern "C" unsigned rt_stack_entry_bytes(int wide) { return wide ? 8u : 4u; }
 
 // occupancy-derived size of the persistent grid
 extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int ldsnodes, unsigned lds_bytes, int *blocks_per_cu,

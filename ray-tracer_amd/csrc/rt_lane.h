@@ -444,7 +444,7 @@ RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx
 // primitive tests are skipped, and a skipped test is one that could not win.
 // Every hit/miss/nearest decision is made by prim_hit in binary64.
 struct Trav {
-    uint32_t cur;        // 16-bit node/leaf reference, RT_CUR_DONE, RT_CUR_DEAD
+    uint32_t cur;        // node / leaf reference, kDone or kDead in the Stack policy's reference form (Stack::Ref)
     int32_t sp;          // stack pointer (entries live in the Stack policy object)
     double best_t;
     uint32_t best_prim;
@@ -492,12 +492,14 @@ template <class Stack>
 RT_HD void trav_pop(Trav &tv, Stack &st) {
     for (;;) {
         if (tv.sp == 0) {
-            tv.cur = RT_CUR_DONE;
+            tv.cur = Stack::Ref::kDone;
             return;
         }
-        const uint32_t e = st.pop(tv.sp);
-        if (bits_f32(e & 0xFFFF0000u) > tv.best32) continue; // stored tnear is rounded DOWN: conservative
-        tv.cur = e & 0xFFFFu;
+        float tnear;
+        uint32_t ref;
+        st.pop(tv.sp, &tnear, &ref);
+        if (tnear > tv.best32) continue; // the stored tnear is a lower bound (16-bit form: rounded DOWN): conservative
+        tv.cur = ref;
         return;
     }
 }
@@ -574,7 +576,7 @@ RT_HD void trav_node_step(const RtNode *nodes, Trav &tv, Stack &st) {
     const uint32_t first = both ? (one_first ? c1 : c0) : (h0 ? c0 : c1);
     const uint32_t second = one_first ? c0 : c1;
     const float second_t = one_first ? tmin0 : tmin1;
-    if (both) st.push(tv.sp, (f32_bits(second_t) & 0xFFFF0000u) | second);
+    if (both) st.push(tv.sp, second_t, second);
     if (h0 || h1)
         tv.cur = first;
     else
@@ -584,7 +586,7 @@ RT_HD void trav_node_step(const RtNode *nodes, Trav &tv, Stack &st) {
 // one leaf step (tv.cur is a leaf reference): binary64 primitive test, then pop
 template <bool GENERAL, int MEDIUM, class Stack>
 RT_HD void trav_leaf_step(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack &st) {
-    const uint32_t pi = tv.cur & RT_REF_MAX;
+    const uint32_t pi = tv.cur & Stack::Ref::kMask;
     const double a = dot(d, d);
     Rec r;
     if (prim_hit<GENERAL, MEDIUM, false>(L, pi, o, d, a, sc, &r, false)) {

@@ -15,11 +15,24 @@
 #define RT_NO_MATERIAL 0xFFFFFFFFu
 #define RT_MAT_KIND_NONE 0xFFu /* in RtPrimMeta::kind bits 8-15: the prim has no material */
 
-// 16-bit child references (stack entries pack one next to a truncated f32 tnear)
-#define RT_REF_LEAF 0x8000u       /* bit 15: leaf, low 15 bits = prim index; else inner node index */
+// Child references.  Scenes of up to 32767 prims and nodes use 16-bit references (a stack entry packs one next to a
+// truncated f32 tnear in ONE LDS word); larger ones 32-bit references (two words per entry) -- struct RtRef16 / RtRef32.
+// A traversal cursor is a reference, or kDone (traversal finished, the lane waits for the shade block), or kDead (no
+// work left for this lane): node < kLeaf <= leaf < kDone < kDead.
+#define RT_REF_LEAF 0x8000u       /* 16-bit form: bit 15 = leaf, low 15 bits = prim index; else inner node index */
 #define RT_REF_MAX 0x7FFFu
-#define RT_CUR_DONE 0x10000u      /* traversal finished, lane waits for the shade block */
-#define RT_CUR_DEAD 0x20000u      /* no work left for this lane */
+#define RT_CUR_DONE 0x10000u
+#define RT_CUR_DEAD 0x20000u
+#define RT_REF_LEAF_W 0x80000000u /* 32-bit form */
+#define RT_REF_MAX_W 0x7FFFFFF0u
+#define RT_CUR_DONE_W 0xFFFFFFFEu
+#define RT_CUR_DEAD_W 0xFFFFFFFFu
+struct RtRef16 {
+    static constexpr uint32_t kLeaf = RT_REF_LEAF, kMask = RT_REF_MAX, kDone = RT_CUR_DONE, kDead = RT_CUR_DEAD;
+};
+struct RtRef32 {
+    static constexpr uint32_t kLeaf = RT_REF_LEAF_W, kMask = 0x7FFFFFFFu, kDone = RT_CUR_DONE_W, kDead = RT_CUR_DEAD_W;
+};
 
 // primitive kinds (leaves of the acceleration structure).  Every leaf is ONE sphere, rectangle or medium under a
 // chain of up to RT_MAX_CHAIN transforms (outermost first): a Sprite whose geometry is a BoundingVolumeHierarchyNode of
@@ -58,7 +71,7 @@ enum RtTextureKind : uint32_t { RT_TEX_SOLID = 0, RT_TEX_CHECKER = 1, RT_TEX_IMA
 struct alignas(16) RtNode {
     float lo_x[2], lo_y[2], lo_z[2]; // [child]
     float hi_x[2], hi_y[2], hi_z[2];
-    uint32_t child[2];               // 16-bit references, see RT_REF_*
+    uint32_t child[2];               // references in the scene's form, see RT_REF_*
     uint32_t pad[2];
 }; // 64 B
 
@@ -130,7 +143,7 @@ struct RtLaunch {
     int32_t n_nodes;
     int32_t stack_entries; // LDS stack entries per lane for this scene (tree depth + 1, <= RT_STACK_DEPTH)
     int32_t swap_cap;      // entries per class queue of the swap-at-shade queues (rt_kernels.hip)
-    uint32_t root;      // 16-bit reference of the BVH root, or RT_CUR_DONE when every prim is hoisted
+    uint32_t root;      // reference of the BVH root in the scene's form, or its kDone when every prim is hoisted
     int32_t n_hoisted;  // prims [0, n_hoisted) are tested directly for every segment
     int32_t n_prims;
     RtCameraD cam;

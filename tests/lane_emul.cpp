@@ -11,22 +11,31 @@
 #include <cstring>
 
 namespace {
+// the LDS stacks of rt_kernels.hip in host memory: the 16-bit form truncates tnear exactly as the device does
+template <class R>
 struct ArrayStack {
-    uint32_t v[RT_STACK_DEPTH];
+    typedef R Ref;
+    float t[RT_STACK_DEPTH];
+    uint32_t r[RT_STACK_DEPTH];
     int high_water = 0;
-    void push(int32_t &sp, uint32_t x) {
-        v[sp++] = x;
+    void push(int32_t &sp, float tnear, uint32_t ref) {
+        t[sp] = R::kLeaf == RT_REF_LEAF ? rtl::bits_f32(rtl::f32_bits(tnear) & 0xFFFF0000u) : tnear;
+        r[sp++] = ref;
         if (sp > high_water) high_water = sp;
     }
-    uint32_t pop(int32_t &sp) { return v[--sp]; }
+    void pop(int32_t &sp, float *tnear, uint32_t *ref) {
+        --sp;
+        *tnear = t[sp];
+        *ref = r[sp];
+    }
 };
 
 // One lane's state machine run to completion: the wave-vote loop of render_kernel only
 // decides WHEN a lane's next step runs, never what it computes.
-template <bool G, int M, bool T, bool LENS>
+template <bool G, int M, bool T, bool LENS, class R = RtRef16>
 void run(const RtLaunch &L, int x0, int y0, int x1, int y1, double *out, double *samples_out, int sx, int sy,
          unsigned long long *cnt, int *stack_high) {
-    ArrayStack st;
+    ArrayStack<R> st;
     for (int y = y0; y < y1; ++y)
         for (int x = x0; x < x1; ++x) {
             rtl::V3 acc = rtl::mk(0, 0, 0);
@@ -38,8 +47,8 @@ void run(const RtLaunch &L, int x0, int y0, int x1, int y1, double *out, double 
                 for (;;) {
                     cnt[1]++;
                     rtl::begin_segment<G, M, T>(L, &ps, tv, st, &cnt[3]);
-                    while (tv.cur != RT_CUR_DONE) {
-                        if (tv.cur < RT_REF_LEAF) {
+                    while (tv.cur != R::kDone) {
+                        if (tv.cur < R::kLeaf) {
                             cnt[2]++;
                             rtl::trav_node_step(L.nodes, tv, st);
                         } else {
@@ -98,7 +107,7 @@ extern "C" int lane_emul_render(rt_scene *s, const rt_camera *cam, int W, int H,
     L.seed_mix = rt_mix64(seed);
     unsigned long long cnt[5] = {0, 0, 0, 0, 0};
     int hw = 0;
-    const bool general = (s->flat.feature_mask & (RT_FEAT_GENERAL | RT_FEAT_MEDIUM | RT_FEAT_TEXTURED)) != 0;
+    const bool general = (s->flat.feature_mask & (RT_FEAT_GENERAL | RT_FEAT_MEDIUM | RT_FEAT_TEXTURED | RT_FEAT_WIDE)) != 0;
     const bool lens = cam->lens_radius != 0.0;
     if (max_depth <= 0) {
         for (int y = y0; y < y1; ++y)
@@ -111,11 +120,16 @@ extern "C" int lane_emul_render(rt_scene *s, const rt_camera *cam, int W, int H,
             run<false, 0, false, true>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
         else
             run<false, 0, false, false>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
-    } else {
+    } else if (!s->flat.wide) {
         if (lens)
             run<true, 2, true, true>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
         else
             run<true, 2, true, false>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
+    } else {
+        if (lens)
+            run<true, 2, true, true, RtRef32>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
+        else
+            run<true, 2, true, false, RtRef32>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
     }
     if (counters) std::memcpy(counters, cnt, sizeof cnt);
     if (stack_high) *stack_high = hw;

@@ -392,11 +392,12 @@ def test_algorithmic_counts_match_committed_fixture(rt, scenes, gpu_device):
         (fx["samples"], fx["segments"], fx["node_steps"], fx["prim_tests"])
 
 
-@pytest.mark.parametrize("n_side", [27, 36, 150])
+@pytest.mark.parametrize("n_side", [27, 36, 150, 200])
 def test_large_lds_footprints(rt, scenes, oracle, gpu_device, n_side):
     """~730 spheres: node copy + stack > 64 KB of dynamic LDS per workgroup (needs the explicit attribute);
     ~1300 spheres: the node array no longer fits next to the stack and stays in global memory;
-    22500 spheres: 1.4 MB of nodes in L2, a deep tree, near the 16-bit reference limit."""
+    22500 spheres: 1.4 MB of nodes in L2, a deep tree, near the 16-bit reference limit;
+    40000 spheres: beyond it -- 32-bit references, two-word stack entries, the general kernel family."""
     rng = np.random.default_rng(n_side)
     d = scenes.SceneDesc()
     g = d.geom("sphere", 0.3)
@@ -412,6 +413,7 @@ def test_large_lds_footprints(rt, scenes, oracle, gpu_device, n_side):
     sc, cam = scenes.build_product(d, device=gpu_device)
     info = sc.info()
     assert info["n_nodes"] == n_side * n_side - 1
+    assert bool(info["feature_mask"] & rt.RT_FEAT_WIDE) == (n_side == 200)
     img = sc.render(cam, 60, 40, 4, 50, seed=3)
     ref = oracle.build_oracle(d).render(60, 40, 4, 50, seed=3, iterative=True, nthreads=8)
     _close(img, ref, max_bad=1)
@@ -553,3 +555,31 @@ def test_device_renders_in_flight_on_two_streams(rt, scenes, gpu_device):
     torch.cuda.synchronize()
     for (W, H, spp, seed), im, ref in zip(jobs, images, want):
         assert np.array_equal(im.cpu().numpy().reshape(H, W, 3), ref), (W, H, spp, seed)
+
+
+def test_bench_two_ranks_rehearsal(gpu_device):
+    """bench.py's N > 1 path end to end on this one-GPU box: two processes (torch.distributed.run, gloo, both on cuda:0) render
+    their tile shards with the HIP kernel, gather, un-permute; rank 0 reports each rank's step anatomy and checks the
+    gathered image against a single-GPU render.  (RCCL itself needs two devices: the driver's scaling run.)"""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device",
+                        "--steps", "1", "--warmup", "0", "--width", "240", "--height", "160", "--spp", "8", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.split("\n") if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["image_matches_single_gpu"] is True
+    assert [a["rank"] for a in d["step_anatomy_ms"]] == [0, 1]
+    assert all(a["render_ms"] > 0 and "gather_ms" in a for a in d["step_anatomy_ms"])
+    assert d["roofline"]["frac"] is None and "N = 1" in d["roofline"]["reason"]

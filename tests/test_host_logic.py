@@ -255,15 +255,18 @@ def test_scene_generators_are_seeded(scenes):
     assert all(1.0 <= hgt < 101.0 for hgt in heights)
 
 
-def test_reference_limits_of_this_build(rt):
-    """16-bit node references: more than 32767 hittable sprites is refused at commit, not mis-rendered."""
-    s = rt.Scene()
-    g = s.sphere(0.1)
-    for i in range(32768):
-        s.sprite(g, None, [1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0, float(i), 0.0, 0.0, 1.0])
-    with pytest.raises(rt.RtError) as e:
-        s.commit(-1)
-    assert e.value.code == -4
+def test_reference_width_follows_the_scene(rt):
+    """up to 32767 prims and nodes: 16-bit node references; one more sprite and the scene commits with 32-bit ones
+    (BoundingVolumeHierarchyNode::new takes any Vec, src/optimize.rs:366)"""
+    def scene(n):
+        s = rt.Scene()
+        g = s.sphere(0.1)
+        for i in range(n):
+            s.sprite(g, None, [1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0, float(i), 0.0, 0.0, 1.0])
+        return s.commit(-1).info()
+    a, b = scene(32767), scene(32768)
+    assert not a["feature_mask"] & rt.RT_FEAT_WIDE and a["n_prims"] == 32767
+    assert b["feature_mask"] & rt.RT_FEAT_WIDE and b["n_prims"] == 32768 and b["n_nodes"] == 32767 and b["max_depth"] <= 24
 
 
 def test_png_writer_restates_main_rs(rt, tmp_path):

@@ -147,3 +147,26 @@ def test_chain_depth_limit_is_reported(rt, scenes):
     with pytest.raises(rt.RtError) as e:
         s.commit(-1)
     assert e.value.code == -4 and "transform levels" in str(e.value)
+
+
+def test_scene_above_the_16_bit_reference_limit_exact(scenes, oracle, lane_emul):
+    """40002 sphere sprites (39999 nodes): 32-bit node references and two-word stack entries; lane program vs oracle"""
+    rng = np.random.default_rng(1)
+    d = scenes.SceneDesc()
+    g = d.geom("sphere", 0.3)
+    mats = [d.lambertian_rgb(rng.uniform(0.1, 0.9, 3)) for _ in range(4)] + [d.mat("metal", d.tex_solid((0.8, 0.8, 0.8)), 0.1),
+                                                                            d.mat("dielectric", 1.5)]
+    n = 200
+    for i in range(n):
+        for j in range(n):
+            d.sprite(g, mats[int(rng.integers(len(mats)))],
+                     scenes.mat4_translation((i - n / 2 + rng.uniform(0, 0.3), 0.3, j - n / 2 + rng.uniform(0, 0.3))))
+    d.sprite(d.geom("sphere", 1000.0), d.lambertian_rgb((0.5, 0.5, 0.5)), scenes.mat4_translation((0.0, -1000.0, 0.0)))
+    d.sprite(d.geom("sphere", 3000.0), d.mat("diffuse_light", d.tex_solid((0.6, 0.7, 1.0))), None)
+    d.camera = ((20.0, 6.0, 8.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 0.5, 1.5, 20.0, 0.02)
+    sc, cam = scenes.build_product(d, device=-1)
+    info = sc.info()
+    assert info["feature_mask"] & rt_feat(scenes, "RT_FEAT_WIDE") and info["n_nodes"] == 39999 and info["n_hoisted"] == 2
+    img, cnt, high = lane_emul.render(sc, cam, 30, 20, 2, 30, 3)
+    assert np.array_equal(img, oracle.build_oracle(d).render(30, 20, 2, 30, 3, iterative=True, nthreads=8))
+    assert high <= info["max_depth"] + 1 <= 24
