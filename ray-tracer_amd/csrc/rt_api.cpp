@@ -30,6 +30,7 @@ extern "C" int rt_kernel_waves_per_simd(unsigned features);
 extern "C" unsigned rt_swap_lds_bytes(unsigned cap);
 extern "C" unsigned rt_swap_cap_max(void);
 extern "C" unsigned rt_stack_entry_bytes(int wide);
+extern "C" unsigned rt_job_lds_bytes(unsigned features);
 extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int ldsnodes, unsigned lds_bytes, int *blocks_per_cu,
                                     int *n_cu);
 extern "C" int rt_launch_unpack(const double *gathered, int tiles_per_shard, int shard_count, int width, int height,
@@ -382,7 +383,8 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     // of it still fit the CU's 160 KiB (book-one: 31 KB of nodes + 12 KB of stack)
     const unsigned block = (unsigned)rt_kernel_block_size(feat);
     const int wide = s->flat.wide ? 1 : 0;
-    const unsigned stack_bytes = (unsigned)L.stack_entries * block * rt_stack_entry_bytes(wide);
+    // traversal stack + the waves' job state (rt_kernels.hip: job_mem)
+    const unsigned stack_bytes = (unsigned)L.stack_entries * block * rt_stack_entry_bytes(wide) + rt_job_lds_bytes(feat);
     const unsigned node_bytes = (unsigned)(s->flat.nodes.size() * sizeof(RtNode));
     const char *no_lds = std::getenv("RT_NO_LDS_NODES");
     // swap-at-shade queues (rt_kernels.hip); RT_SWAP=0 selects the kernels without them (A/B runs)

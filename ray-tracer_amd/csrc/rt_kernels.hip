@@ -208,6 +208,7 @@ __device__ __forceinline__ void store_sample(double *samples, uint32_t slot, rtl
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) { // set bits below this lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
+// first active lane's value, for values that are the same in every lane
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // Dynamic LDS: [stack_entries][RT_BLOCK] traversal stack, then (LDSNODES) a copy of the
@@ -231,7 +232,11 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
     const unsigned node_lds_bytes = LDSNODES ? (unsigned)L.n_nodes * (unsigned)sizeof(RtNode) : 0u;
     // swap queues: header {state[3], pad...}: state = entries in the queue | kSwapLock while a wave works on it; then per class RT_SWAP_F64 arrays of CAP doubles and
     // RT_SWAP_F32 arrays of CAP words (field-major: consecutive entries are consecutive addresses)
-    unsigned char *swap_mem = rt_lds + (size_t)L.stack_entries * kBlock * kStackEntry + node_lds_bytes;
+    // per-wave job state (8 words per wave): it only changes in the refill step, and as loop-carried registers its seven
+    // words were copied out and back on every trip round the vote loop (25 v_mov per node-block visit)
+    uint32_t *job_mem = reinterpret_cast<uint32_t *>(rt_lds + (size_t)L.stack_entries * kBlock * kStackEntry + node_lds_bytes) + (threadIdx.x >> 6) * 8u;
+    if ((threadIdx.x & 63u) < 8u) job_mem[threadIdx.x & 63u] = (threadIdx.x & 63u) == 6u ? 1u : 0u; // job_nspp = 1, the rest 0
+    unsigned char *swap_mem = rt_lds + (size_t)L.stack_entries * kBlock * kStackEntry + node_lds_bytes + (kBlock / 64) * 32;
     uint32_t *swap_hdr = reinterpret_cast<uint32_t *>(swap_mem);
     if (SWAP && threadIdx.x < RT_SWAP_HDR_BYTES / 4u) swap_hdr[threadIdx.x] = 0u;
     if (LDSNODES) {
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
         for (int i = (int)threadIdx.x; i < n16; i += kBlock) dst[i] = src[i];
         nodes = reinterpret_cast<const RtNode *>(dst);
     }
-    if (LDSNODES || SWAP) __syncthreads();
+    __syncthreads();
 
     rtl::PathState ps;
     rtl::Trav tv;
@@ -253,7 +258,6 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
     uint32_t slot = 0; // index of this lane's sample in L.samples
 
     // wave-uniform job state
-    uint32_t job_next = 0, job_left = 0, job_slot0 = 0, job_x0 = 0, job_y0 = 0, job_s_first = 0, job_nspp = 1;
     bool queue_empty = false;
 
     unsigned long long c_nodes = 0, c_prims = 0, c_segs = 0, c_draws = 0, c_samples = 0;
@@ -524,6 +528,21 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
             t_fin += t1 - t0;
             // refill: lanes without a path take the next samples of the job queue.  Executed by the
             // whole wave (wave-uniform control flow) so the job state stays identical in every lane.
+            // The loop only hands out (pixel, sample, slot); the samples themselves are started once, after it: the path
+            // state does not travel through the loop's back edge (the compiler copied ~36 registers per trip when it did)
+            uint32_t new_x = 0, new_y = 0, new_s = 0;
+            bool got = false;
+            uint32_t job_next = 0, job_left = 0, job_slot0 = 0, job_x0 = 0, job_y0 = 0, job_s_first = 0, job_nspp = 1;
+            if (do_refill) { // wave-uniform
+                const uint4 ja = *reinterpret_cast<const uint4 *>(job_mem), jb = *reinterpret_cast<const uint4 *>(job_mem + 4);
+                job_next = uniform(ja.x);
+                job_left = uniform(ja.y);
+                job_slot0 = uniform(ja.z);
+                job_x0 = uniform(ja.w);
+                job_y0 = uniform(jb.x);
+                job_s_first = uniform(jb.y);
+                job_nspp = uniform(jb.z);
+            }
             while (do_refill) {
                 const unsigned long long m = __ballot(need);
                 if (m == 0ull) break;
@@ -558,14 +577,24 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                     const uint32_t x = job_x0 + (pix & 7u), y = job_y0 + (pix >> 3);
                     if (x < (uint32_t)L.width && y < (uint32_t)L.height) {
                         slot = job_slot0 + sj * RT_TILE_PIXELS + pix;
-                        rtl::start_sample<LENS>(L, x, y, (uint32_t)L.s0 + job_s_first + sj, &ps);
-                        has_path = true;
+                        new_x = x;
+                        new_y = y;
+                        new_s = (uint32_t)L.s0 + job_s_first + sj;
+                        got = true;
                         need = false;
                     }
                     // a pixel outside the image consumes its slot and the lane asks again
                 }
                 job_next += take;
                 job_left -= take;
+            }
+            if (do_refill && (threadIdx.x & 63u) == 0u) {
+                *reinterpret_cast<uint4 *>(job_mem) = make_uint4(job_next, job_left, job_slot0, job_x0);
+                *reinterpret_cast<uint4 *>(job_mem + 4) = make_uint4(job_y0, job_s_first, job_nspp, 0u);
+            }
+            if (got) {
+                rtl::start_sample<LENS>(L, new_x, new_y, new_s, &ps);
+                has_path = true;
             }
             RT_STAMP(t0);
             t_ref += t0 - t1;
@@ -775,6 +804,7 @@ extern "C" unsigned rt_swap_lds_bytes(unsigned cap) {
 }
 extern "C" unsigned rt_swap_cap_max(void) { return RT_SWAP_CAP; }
 extern "C" unsigned rt_stack_entry_bytes(int wide) { return wide ? 8u : 4u; }
+extern "C" unsigned rt_job_lds_bytes(unsigned features) { return (unsigned)(rt_kernel_block_size(features) / 64) * 32u; }
 
 // occupancy-derived size of the persistent grid
 extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int ldsnodes, unsigned lds_bytes, int *blocks_per_cu,
