@@ -366,6 +366,7 @@ struct Leaf {
     Aabb bound{};
     std::vector<Link> chain;
     std::vector<Shape> boundary; // RT_PRIM_MEDIUM_C
+    bool unbounded = false;      // hits may lie anywhere on the ray, not only inside `bound` (a medium over an open boundary)
 };
 
 // the shape's bound carried through every level of `outer` + `inner` (outermost first): the AABB of the 8 transformed
@@ -458,6 +459,38 @@ struct Flattener {
             return fail(RT_ERR_UNSUPPORTED, "a ConstantMedium inside the boundary of another ConstantMedium is not supported");
         }
         return true;
+    }
+
+    // Does `gi`, seen from the frame of the ConstantMedium around it, enclose a volume whose FIRST hit from outside always
+    // has normal . direction < 0?  Then a medium hit is never nearer than the ray's entry into the boundary's box and the
+    // box may cull it.  True for a sphere, a cube (outward faces, src/geometry.rs:254-285) and unions of those moved by pure
+    // translations.  A rectangle's normal is +z from either side (src/geometry.rs:176), and a general matrix carries
+    // normals by M rather than M^-T (quirk Q5): with those, volume.rs:80-98 ("the origin is inside") fires for origins far
+    // outside the box and returns t = distance < the box entry.  (Measure-zero leftovers: rays through the 1e-16-wide seams
+    // of a cube's faces, spheres grazed with a discriminant that rounds to 0.)
+    bool boundary_encloses(int gi, int depth) {
+        if (depth > 16) return false;
+        const GeometryIR &g = ir.geometries[(size_t)gi];
+        switch (g.kind) {
+        case GEO_SPHERE:
+        case GEO_CUBE:
+            return true;
+        case GEO_TRANSFORMED: {
+            Link l;
+            if (!make_link(g.M, &l)) return true; // never hit
+            return l.translation && boundary_encloses(g.boundary, depth + 1);
+        }
+        case GEO_BVH:
+            for (int si : g.children) {
+                const SpriteIR &sp = ir.sprites[(size_t)si];
+                Link l;
+                if (sp.geometry < 0 || !make_link(sp.M, &l)) continue;
+                if (!l.translation || !boundary_encloses(sp.geometry, depth + 1)) return false;
+            }
+            return true;
+        default:
+            return false;
+        }
     }
 
     void finish_meta(RtPrimMeta *m, const std::vector<Link> &chain) {
@@ -558,6 +591,7 @@ struct Flattener {
                     first = false;
                 }
                 if (first) return true; // empty boundary: never hit
+                lf.unbounded = !boundary_encloses(g.boundary, depth + 1);
                 fs.feature_mask |= RT_FEAT_GENERAL | RT_FEAT_MEDIUM_GENERAL;
             }
             pad(&lf.bound);
@@ -657,11 +691,16 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
     std::vector<size_t> order(leaves.size());
     std::iota(order.begin(), order.end(), (size_t)0);
     std::vector<size_t> hoist;
+    // media over an open boundary first, however many: no box bounds where they can be hit (Flattener::boundary_encloses)
+    for (size_t i = 0; i < leaves.size(); ++i)
+        if (leaves[i].unbounded) hoist.push_back(i);
+    const size_t n_forced = hoist.size();
     {
         // peel off the largest box while it still fills >= 10 % of the box of what is left (sky first, then the ground
         // under it, ...): judged against the REMAINING prims, so a big ground inside a much bigger sky still qualifies
         std::vector<char> gone(leaves.size(), 0);
-        while ((int)hoist.size() < RT_MAX_HOISTED && hoist.size() + 1 < leaves.size()) {
+        for (size_t i : hoist) gone[i] = 1;
+        while ((int)(hoist.size() - n_forced) < RT_MAX_HOISTED && hoist.size() + 1 < leaves.size()) {
             bool first = true;
             Aabb root{};
             size_t big = 0;

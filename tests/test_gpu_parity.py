@@ -300,6 +300,17 @@ def test_instanced_scene_matches_oracle(rt, scenes, oracle, gpu_device):
     _close(img, oracle.build_oracle(d).render(100, 80, 16, 60, seed=3, iterative=True, nthreads=8), max_bad=4)
 
 
+def test_media_over_open_boundaries_match_oracle(rt, scenes, oracle, gpu_device):
+    """ConstantMedium over a rectangle / rotated or squeezed spheres: hits in front of every box of the boundary, so these
+    media are tested for every segment (tests/test_lane_parity_cpu.py::open_boundary_media)"""
+    from test_lane_parity_cpu import open_boundary_media
+    d = open_boundary_media(scenes)
+    sc, cam = scenes.build_product(d, device=gpu_device)
+    assert sc.info()["n_hoisted"] >= 4
+    img = sc.render(cam, 128, 96, 16, 40, seed=5)
+    _close(img, oracle.build_oracle(d, bvh_seed=11).render(128, 96, 16, 40, seed=5, iterative=True, nthreads=8), max_bad=4)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_scenes_match_oracle(rt, scenes, oracle, gpu_device, seed):
     """Random transforms (incl. non-rigid), cubes, media, textures, lens: general kernel vs oracle."""

@@ -3,6 +3,8 @@ lane by lane over the committed flat scene, against the oracle.  This checks the
 flattener, the SAH BVH with binary32 culling, the hoisting and every per-lane formula on
 machines without a GPU; it claims nothing about the GPU itself (see test_gpu_parity.py).
 Both sides use the host libm here, so agreement must be exact, pixel for pixel."""
+import math
+
 import numpy as np
 import pytest
 
@@ -130,6 +132,46 @@ def test_instanced_nodes_and_general_media_exact(scenes, oracle, lane_emul):
     # the tree and the world's form do not matter (F7), nested nodes included
     for kw in ({"bvh_seed": 99}, {"world": "list"}):
         assert np.array_equal(img, oracle.build_oracle(d, **kw).render(50, 40, 6, 60, 3, iterative=True, nthreads=8))
+
+
+def open_boundary_media(scenes):
+    """ConstantMedium<Rectangle>, ConstantMedium over a rotated sphere pair and over a scaled sphere: boundaries that do not
+    enclose a volume in the sense of src/volume.rs:49 (a rectangle's normal is +z from both sides; general matrices move
+    normals by M, quirk Q5).  For a ray that meets such a boundary from its back, volume.rs:80-98 scatters anywhere between
+    the ray's ORIGIN and the boundary -- in front of every box the boundary has.  Solid objects in between must not cull it."""
+    d = scenes.SceneDesc(name="open-boundary media")
+    grey, red = d.lambertian_rgb((0.7, 0.7, 0.7)), d.lambertian_rgb((0.7, 0.1, 0.1))
+    fog = [d.mat("isotropic", d.tex_solid(c)) for c in ((0.9, 0.9, 0.9), (0.2, 0.3, 0.9), (0.2, 0.8, 0.3))]
+    ey = (0.0, 1.0, 0.0)
+    # a rectangle whose +z looks away from the camera: every camera ray through it starts "inside"
+    d.sprite(d.geom("medium", d.geom("rectangle", 6.0, 4.0), 0.05), fog[0], scenes.mat4_translation((-3.0, 0.0, 14.0)))
+    # the same seen from its front (never hit: the restarted ray misses, volume.rs:75-77)
+    d.sprite(d.geom("medium", d.geom("rectangle", 3.0, 3.0), 0.5), fog[1],
+             scenes.mat4_multiplied(scenes.mat4_translation((4.0, 2.0, 10.0)), scenes.mat4_rotation(math.pi, ey)))
+    # two spheres under a rotation inside the boundary, and a sphere squeezed by a non-rigid matrix
+    pair = d.geom("bvh", [d.sprite(d.geom("sphere", 1.0), None, scenes.mat4_multiplied(scenes.mat4_translation((dx, 0.0, 0.0)), scenes.mat4_rotation(0.4, ey)))
+                          for dx in (-0.7, 0.7)])
+    d.sprite(d.geom("medium", pair, 0.8), fog[2], scenes.mat4_translation((3.0, -1.5, 9.0)))
+    squeeze = [1.0, 0.0, 0.0, 0.0, 0.9, 0.25, 0.0, 0.0, 0.0, 0.0, 3.0, 0.0, 0.0, 0.0, 0.0, 1.0]
+    d.sprite(d.geom("medium", d.geom("transformed", d.geom("sphere", 1.0), squeeze), 0.6), fog[1], scenes.mat4_translation((-4.0, 2.5, 11.0)))
+    # solid things between the camera and the media
+    for k, (x, y, z) in enumerate([(-3.5, 0.5, 6.0), (-2.0, -1.0, 8.0), (0.5, 0.3, 5.0), (3.0, -1.0, 6.5), (-4.5, 2.0, 7.0)]):
+        d.sprite(d.geom("sphere", 0.6), red if k % 2 else grey, scenes.mat4_translation((x, y, z)))
+    d.sprite(d.geom("sphere", 60.0), d.mat("diffuse_light", d.tex_solid((0.8, 0.8, 0.8))), None)
+    d.camera = ((0.0, 0.5, -2.0), (0.0, 0.0, 10.0), (0.0, 1.0, 0.0), 0.9, 4 / 3, 10.0, 0.0)
+    return d
+
+
+def test_media_over_open_boundaries_exact(scenes, oracle, lane_emul):
+    d = open_boundary_media(scenes)
+    sc, cam = scenes.build_product(d, device=-1)
+    info = sc.info()
+    assert info["n_hoisted"] >= 4  # the four media (+ the enclosing light): tested for every segment, no box culls them
+    img, cnt, high = lane_emul.render(sc, cam, 64, 48, 8, 40, 5)
+    for kw in ({}, {"bvh_seed": 42}, {"world": "list"}):
+        ref, ocnt = oracle.build_oracle(d, **kw).render(64, 48, 8, 40, 5, iterative=True, nthreads=8, counters=True)
+        assert np.array_equal(img, ref)
+    assert cnt["segments"] == ocnt["segments"] > 64 * 48 * 8 * 1.1  # the fog in front of the rectangle scatters
 
 
 def rt_feat(scenes, name):

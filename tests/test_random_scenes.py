@@ -42,6 +42,40 @@ def random_scene(scenes, seed):
             M = scenes.mat4_multiplied(M, S)
         return M
 
+    def basic_geometry(cube=True):
+        g = rng.integers(0, 3 if cube else 2)
+        if g == 0:
+            return d.geom("sphere", float(rng.uniform(0.2, 1.2)))
+        if g == 1:
+            return d.geom("rectangle", float(rng.uniform(0.5, 3)), float(rng.uniform(0.5, 3)))
+        return d.geom("cube", float(rng.uniform(0.4, 1.5)), float(rng.uniform(0.4, 1.5)), float(rng.uniform(0.4, 1.5)))
+
+    def node(depth=0):
+        """a BoundingVolumeHierarchyNode used as a geometry: 2-5 children (sprites with or without a material of their own,
+        one of them possibly another node or a medium), to be instanced by the sprites that carry it"""
+        kids = []
+        for _ in range(int(rng.integers(2, 6))):
+            c = rng.integers(0, 10)
+            if c == 0 and depth == 0:
+                geo = node(1)
+            elif c == 1:
+                geo = d.geom("medium", basic_geometry(), float(rng.uniform(0.2, 2.0)))
+            elif c == 2:
+                # (a cube's faces are one more level: RT_MAX_CHAIN = 4 transforms above a leaf)
+                geo = d.geom("transformed", basic_geometry(cube=depth == 0), transform(rng.uniform(-0.5, 0.5, 3)))
+            else:
+                geo = basic_geometry()
+            kids.append(d.sprite(geo, None if rng.random() < 0.7 else material(), transform(rng.uniform(-1.5, 1.5, 3))))
+        return d.geom("bvh", kids)
+
+    if rng.random() < 0.6:  # instancing (src/sprite.rs:87-93 with T = BoundingVolumeHierarchyNode)
+        cluster = node()
+        for _ in range(int(rng.integers(1, 4))):
+            pos = rng.uniform(-6, 6, 3) + np.array([0, 0, 12.0])
+            m = material()
+            if d.materials[m][0] == "isotropic":
+                m = d.mat("isotropic", int(tex[rng.integers(4)]))  # media inside the node: solid colours keep the usual kernel family
+            d.sprite(cluster, m, transform(pos))
     n = int(rng.integers(3, 40))
     for _ in range(n):
         pos = rng.uniform(-6, 6, 3) + np.array([0, 0, 12.0])
@@ -53,7 +87,12 @@ def random_scene(scenes, seed):
         elif g < 9:
             geo = d.geom("cube", float(rng.uniform(0.5, 2)), float(rng.uniform(0.5, 2)), float(rng.uniform(0.5, 2)))
         else:
-            geo = d.geom("medium", d.geom("sphere", float(rng.uniform(0.5, 2.0))), float(rng.uniform(0.1, 2.0)))
+            b = rng.integers(0, 4)  # ConstantMedium<T: Hit>: mostly the examples' sphere, sometimes a cube / a rectangle pair / a node
+            boundary = d.geom("sphere", float(rng.uniform(0.5, 2.0))) if b < 2 else (
+                d.geom("cube", float(rng.uniform(0.8, 2)), float(rng.uniform(0.8, 2)), float(rng.uniform(0.8, 2))) if b == 2 else
+                d.geom("bvh", [d.sprite(d.geom("sphere", float(rng.uniform(0.5, 1.2))), None, scenes.mat4_translation(rng.uniform(-0.6, 0.6, 3)))
+                               for _ in range(2)]))
+            geo = d.geom("medium", boundary, float(rng.uniform(0.1, 2.0)))
         mat = None if rng.random() < 0.05 else material()
         if d.geometries[geo][0] == "medium":
             mat = d.mat("isotropic", int(tex[rng.integers(4)]))
