@@ -247,6 +247,8 @@ typedef struct rt_scene_info {
     int node_bytes, prim_bytes, material_bytes; /* bytes one traversal step / test reads */
     unsigned feature_mask;                      /* RT_FEAT_* present in the scene */
     size_t device_bytes;                        /* total resident bytes after upload */
+    int n_list;         /* > 0: a small general scene walked as a LIST of this many leaf boxes, all tested in lock step by the
+                         * wave, instead of the tree (the tree is still built and reported); nodes_visited then counts boxes */
 } rt_scene_info;
 int rt_scene_get_info(const rt_scene *, rt_scene_info *out);
 /* copy of the flat BVH: 28 doubles per node

@@ -61,7 +61,7 @@ class rt_scene_info(C.Structure):
                 ("max_depth", C.c_int),
                 ("n_materials", C.c_int), ("n_textures", C.c_int), ("n_xforms", C.c_int), ("node_bytes", C.c_int),
                 ("prim_bytes", C.c_int), ("material_bytes", C.c_int), ("feature_mask", C.c_uint),
-                ("device_bytes", C.c_size_t)]
+                ("device_bytes", C.c_size_t), ("n_list", C.c_int)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

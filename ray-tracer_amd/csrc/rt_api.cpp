@@ -286,7 +286,8 @@ static void fill_launch(const rt_scene *s, const rt_camera *cam, const rt_render
     L->textures = (const RtTexture *)s->d_textures;
     L->image_blob = (const uint8_t *)s->d_blob;
     L->n_nodes = (int)s->flat.nodes.size();
-    L->stack_entries = std::min(RT_STACK_DEPTH, s->flat.max_depth + 1);
+    L->n_list = s->flat.n_list;
+    L->stack_entries = s->flat.n_list ? s->flat.n_list - 1 : std::min(RT_STACK_DEPTH, s->flat.max_depth + 1);
     L->root = s->flat.root;
     L->n_hoisted = s->flat.n_hoisted;
     L->n_prims = s->flat.n_leaf_prims;
@@ -401,15 +402,16 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
         if (other + hdr + 16u * per_entry > lds_share) return 16u; // does not fit anyway: fewer groups will be resident
         return std::min(rt_swap_cap_max(), (lds_share - other - hdr) / per_entry);
     };
-    const int ldsnodes = !wide && node_bytes > 0 && stack_bytes + node_bytes + (swap ? rt_swap_lds_bytes(block >= 512u ? 0u : 32u) : 0u) <= lds_share &&
-                         !(no_lds && *no_lds == '1');
+    const int list = s->flat.n_list > 0; // the box list (< 1 KB) always lives in LDS
+    const int ldsnodes = list || (!wide && node_bytes > 0 && stack_bytes + node_bytes + (swap ? rt_swap_lds_bytes(block >= 512u ? 0u : 32u) : 0u) <= lds_share &&
+                                  !(no_lds && *no_lds == '1'));
     const unsigned swap_cap = swap_cap_that_fits(stack_bytes + (ldsnodes ? node_bytes : 0u));
     const unsigned swap_bytes = swap ? rt_swap_lds_bytes(swap_cap) : 0u;
     L.swap_cap = (int)swap_cap;
     const unsigned lds_bytes = stack_bytes + (ldsnodes ? node_bytes : 0u) + swap_bytes;
-    const int lds_mode = (ldsnodes ? 1 : 0) | (swap ? 2 : 0) | (wide ? 4 : 0);
+    const int lds_mode = (ldsnodes ? 1 : 0) | (swap ? 2 : 0) | (wide ? 4 : 0) | (list ? 8 : 0);
     int per_cu = 0, n_cu = 0, rc = 0;
-    const unsigned occ_key = feat | (lens ? 8u : 0u) | (count ? 16u : 0u) | ((unsigned)lds_mode << 5);
+    const unsigned occ_key = feat | (lens ? 16u : 0u) | (count ? 32u : 0u) | ((unsigned)lds_mode << 6); // feat uses bits 0-3
     if (s->occ_key == occ_key && s->occ_lds == lds_bytes) {
         per_cu = s->occ_per_cu;
         n_cu = s->occ_n_cu;
@@ -745,12 +747,13 @@ int rt_scene_get_info(const rt_scene *s, rt_scene_info *out) {
     out->n_prims = s->flat.n_leaf_prims;
     out->n_child_prims = (int)s->flat.prim_meta.size() - s->flat.n_leaf_prims;
     out->n_hoisted = s->flat.n_hoisted;
-    out->n_nodes = (int)s->flat.nodes.size();
+    out->n_nodes = (int)s->flat.host_nodes.size();
+    out->n_list = s->flat.n_list;
     out->max_depth = s->flat.max_depth;
     out->n_materials = (int)s->flat.materials.size();
     out->n_textures = (int)s->flat.textures.size();
     out->n_xforms = (int)s->flat.xforms.size();
-    out->node_bytes = (int)sizeof(RtNode);
+    out->node_bytes = s->flat.n_list ? RT_LIST_BOX_FLOATS * (int)sizeof(float) : (int)sizeof(RtNode); // per node step | per list box
     out->prim_bytes = (int)sizeof(RtPrimGeo);
     out->material_bytes = (int)sizeof(RtMaterial);
     out->feature_mask = s->flat.feature_mask;
@@ -764,21 +767,20 @@ int rt_scene_copy_nodes(const rt_scene *s, double *out, int max_nodes) {
     const int n = (int)s->flat.host_nodes.size();
     for (int i = 0; i < n && i < max_nodes; ++i) {
         const rt::HostNode &nd = s->flat.host_nodes[(size_t)i];
-        const RtNode &cn = s->flat.nodes[(size_t)i];
         double *o = out + (size_t)i * 28;
         for (int c = 0; c < 2; ++c) {
+            float clo[3], chi[3];
+            rt::cull_box(nd.box[c], clo, chi); // what the device array holds (a list-mode scene keeps these boxes per leaf)
             for (int k = 0; k < 3; ++k) {
                 o[c * 6 + k] = nd.box[c].lo[k];
                 o[c * 6 + 3 + k] = nd.box[c].hi[k];
             }
             o[12 + c] = (double)nd.child[c];
             // the binary32 culling box actually traversed
-            o[14 + c * 6 + 0] = cn.lo_x[c];
-            o[14 + c * 6 + 1] = cn.lo_y[c];
-            o[14 + c * 6 + 2] = cn.lo_z[c];
-            o[14 + c * 6 + 3] = cn.hi_x[c];
-            o[14 + c * 6 + 4] = cn.hi_y[c];
-            o[14 + c * 6 + 5] = cn.hi_z[c];
+            for (int k = 0; k < 3; ++k) {
+                o[14 + c * 6 + k] = clo[k];
+                o[14 + c * 6 + 3 + k] = chi[k];
+            }
         }
         o[26] = o[27] = 0.0;
     }

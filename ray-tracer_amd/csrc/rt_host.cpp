@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -789,6 +790,32 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
     } else {
         fs.root = RT_CUR_DONE; // every prim is hoisted (only possible in the 16-bit form)
         fs.max_depth = 0;
+    }
+    // Small general scenes (the Cornell box: 18 leaves) are walked as a LIST: every lane of a wave tests all the leaves'
+    // culling boxes in lock step (rtl::trav_list_step) instead of descending a five-level tree with half the wave idle, then
+    // the binary64 tests run nearest box first exactly as after a tree walk.  Same boxes as the tree's leaf boxes (cull_box),
+    // same binary64 tests, same tie rule: which boxes are looked at first never reaches a result.  The reference's own
+    // counterpart is the linear scan of a `Vec` world (src/geometry.rs:76-116).  The tree is still built (inspection, tests);
+    // the device gets the box list in the node array's place.  RT_NO_LIST=1 keeps the tree walk (A/B runs).
+    const int n_bvh_leaves = fs.n_leaf_prims - fs.n_hoisted;
+    const char *no_list = std::getenv("RT_NO_LIST");
+    if ((fs.feature_mask & RT_FEAT_GENERAL) && !fs.wide && n_bvh_leaves >= 2 && n_bvh_leaves <= RT_LIST_MAX && !(no_list && *no_list == '1')) {
+        fs.n_list = n_bvh_leaves;
+        std::vector<float> packed((size_t)n_bvh_leaves * RT_LIST_BOX_FLOATS, 0.0f);
+        for (int i = 0; i < n_bvh_leaves; ++i) {
+            float lo[3], hi[3];
+            cull_box(fs.prim_bounds[(size_t)(fs.n_hoisted + i)], lo, hi);
+            for (int a = 0; a < 3; ++a) {
+                float *p = &packed[(size_t)i * RT_LIST_BOX_FLOATS + (size_t)a * 3];
+                p[0] = lo[a];
+                p[1] = hi[a];
+                p[2] = lo[a];
+            }
+        }
+        const size_t per = sizeof(RtNode) / sizeof(float);
+        fs.nodes.assign((packed.size() + per - 1) / per, RtNode{});
+        std::memcpy(fs.nodes.data(), packed.data(), packed.size() * sizeof(float));
+        fs.root = 0u; // "at a node": the list step runs first (stack need: every box but the nearest may be pushed, n_list - 1)
     }
     // the material's kind rides in the prim's meta word (RtPrimMeta::kind bits 8-15)
     for (RtPrimMeta &m : fs.prim_meta) {

@@ -216,7 +216,8 @@ __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__bui
 // in ~1/4 of an L2 hit.
 extern __shared__ __attribute__((aligned(16))) unsigned char rt_lds[];
 
-template <bool GENERAL, int MEDIUM, bool TEXTURED, bool LENS, bool COUNT, bool LDSNODES, bool SWAP, bool WIDE>
+// LIST: the scene's leaves are a box list in LDS instead of a tree (small general scenes, rtl::trav_list_step)
+template <bool GENERAL, int MEDIUM, bool TEXTURED, bool LENS, bool COUNT, bool LDSNODES, bool SWAP, bool WIDE, bool LIST>
 __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM)) void render_kernel(const RtLaunch L) {
     constexpr int kBlock = block_of(GENERAL, MEDIUM);
     typedef typename StackOf<kBlock, WIDE>::type Stack;
@@ -619,6 +620,18 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
         } else {
             // ---------------- node block ----------------
             RT_STAMP(t0);
+            if constexpr (LIST) {
+                // one step: all the leaves' boxes, every lane in lock step; the lanes leave as LEAF or DONE
+                const bool at_node = tv.cur < Ref::kLeaf;
+                if (COUNT && counting_lane) {
+                    ++c_nw;
+                    c_nl += (unsigned long long)nN;
+                }
+                if (at_node) {
+                    if (COUNT) c_nodes += (unsigned long long)L.n_list;
+                    rtl::trav_list_step(reinterpret_cast<const float *>(nodes), (uint32_t)L.n_list, (uint32_t)L.n_hoisted, tv, st);
+                }
+            } else
             for (;;) {
                 const bool at_node = tv.cur < Ref::kLeaf;
                 const int n = __popcll(__ballot(at_node));
@@ -737,9 +750,9 @@ __global__ void probe_math_kernel(const double *a, const double *b, int n, doubl
 // ---- dispatch over the template instantiations ----
 typedef void (*KernelFn)(const RtLaunch);
 
-template <bool GENERAL, int MEDIUM, bool TEXTURED, bool SWAP, bool WIDE = false>
+template <bool GENERAL, int MEDIUM, bool TEXTURED, bool SWAP, bool WIDE = false, bool LIST = false>
 KernelFn pick3(bool lens, bool count, bool ldsnodes) {
-#define RT_PICK(LN, C, LD) return render_kernel<GENERAL, MEDIUM, TEXTURED, LN, C, LD && !WIDE, SWAP, WIDE>
+#define RT_PICK(LN, C, LD) return render_kernel<GENERAL, MEDIUM, TEXTURED, LN, C, (LD && !WIDE) || LIST, SWAP, WIDE, LIST>
     if (lens) {
         if (count) {
             if (ldsnodes) RT_PICK(true, true, true); else RT_PICK(true, true, false);
@@ -755,9 +768,15 @@ KernelFn pick3(bool lens, bool count, bool ldsnodes) {
     }
 #undef RT_PICK
 }
-// lds_mode: bit 0 = node array copied to LDS, bit 1 = swap-at-shade queues, bit 2 = 32-bit references (general families)
+// lds_mode: bit 0 = node array copied to LDS, bit 1 = swap-at-shade queues, bit 2 = 32-bit references (general families),
+// bit 3 = box list instead of the tree (general families, 16-bit references, always in LDS)
 KernelFn pick(unsigned features, bool lens, bool count, int lds_mode) {
-    const bool ldsnodes = (lds_mode & 1) != 0, swap = (lds_mode & 2) != 0, wide = (lds_mode & 4) != 0;
+    const bool ldsnodes = (lds_mode & 1) != 0, swap = (lds_mode & 2) != 0, wide = (lds_mode & 4) != 0, list = (lds_mode & 8) != 0;
+    if (list) {
+        if (features == 1u) return swap ? pick3<true, 0, false, true, false, true>(lens, count, true) : pick3<true, 0, false, false, false, true>(lens, count, true);
+        if (features & 8u) return swap ? pick3<true, 2, true, true, false, true>(lens, count, true) : pick3<true, 2, true, false, false, true>(lens, count, true);
+        return swap ? pick3<true, 1, true, true, false, true>(lens, count, true) : pick3<true, 1, true, false, false, true>(lens, count, true);
+    }
     if (wide) { // more than 32767 prims or nodes: the node array never fits LDS
         if ((features & ~1u) == 0u) return swap ? pick3<true, 0, false, true, true>(lens, count, false) : pick3<true, 0, false, false, true>(lens, count, false);
         if (features & 8u) return swap ? pick3<true, 2, true, true, true>(lens, count, false) : pick3<true, 2, true, false, true>(lens, count, false);

@@ -523,9 +523,11 @@ RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack
     tv.fy = -(qy - ey);
     tv.fz = -(qz - ez);
     // sign bit of 1/d picks the entry plane of each axis (an infinite or NaN reciprocal only ever removes constraints)
-    tv.ox = (f32_bits(tv.idx) >> 31) * 24u;
-    tv.oy = (f32_bits(tv.idy) >> 31) * 24u + 8u;
-    tv.oz = (f32_bits(tv.idz) >> 31) * 24u + 16u;
+    // (list mode, trav_list_step: byte offset inside a list box of the {entry, exit} plane pair of each axis)
+    const uint32_t flip = L.n_list ? 4u : 24u, ay = L.n_list ? 12u : 8u, az = L.n_list ? 24u : 16u;
+    tv.ox = (f32_bits(tv.idx) >> 31) * flip;
+    tv.oy = (f32_bits(tv.idy) >> 31) * flip + ay;
+    tv.oz = (f32_bits(tv.idz) >> 31) * flip + az;
     tv.best_t = RTL_INF;
     tv.best_prim = 0xFFFFFFFFu;
     const double a = dot(d, d);
@@ -581,6 +583,41 @@ RT_HD void trav_node_step(const RtNode *nodes, Trav &tv, Stack &st) {
         tv.cur = first;
     else
         trav_pop(tv, st);
+}
+
+// List mode (small general scenes, RtLaunch::n_list > 0): ONE step tests the culling boxes of all n leaves -- every lane of
+// the wave the same box at the same time, no divergence, no stack traffic for misses -- keeps the nearest box in registers
+// and pushes the others; the leaf steps that follow test the nearest first and pop the rest against the shrinking best hit,
+// exactly as after a tree walk.  Box b is leaf prim first_prim + b; its record is {lo, hi, lo} per axis, so the lane's
+// entry plane of an axis sits at byte tv.o? and its exit plane 4 bytes on (two adjacent words: one ds_read2_b32 per axis).
+template <class Stack>
+RT_HD void trav_list_step(const float *boxes, uint32_t n, uint32_t first_prim, Trav &tv, Stack &st) {
+    typedef typename Stack::Ref Ref;
+    const unsigned char *base = reinterpret_cast<const unsigned char *>(boxes);
+    const float *bx = reinterpret_cast<const float *>(base + tv.ox), *by = reinterpret_cast<const float *>(base + tv.oy),
+                *bz = reinterpret_cast<const float *>(base + tv.oz);
+    float near_t = 0.0f;
+    uint32_t near_ref = Ref::kDone;
+    for (uint32_t b = 0; b < n; ++b) {
+        const float tmin = fmaxf(fmaxf(fmaf(bx[0], tv.idx, tv.nx), fmaf(by[0], tv.idy, tv.ny)), fmaxf(fmaf(bz[0], tv.idz, tv.nz), 0.0f));
+        const float tmax = fminf(fminf(fmaf(bx[1], tv.idx, tv.fx), fmaf(by[1], tv.idy, tv.fy)), fminf(fmaf(bz[1], tv.idz, tv.fz), tv.best32));
+        if (tmin <= tmax * 1.000002f) { // the same test, slack included, as a child box of trav_node_step
+            const uint32_t ref = Ref::kLeaf | (first_prim + b);
+            if (near_ref == Ref::kDone) {
+                near_t = tmin;
+                near_ref = ref;
+            } else {
+                const bool nearer = tmin < near_t;
+                st.push(tv.sp, nearer ? near_t : tmin, nearer ? near_ref : ref);
+                near_t = nearer ? tmin : near_t;
+                near_ref = nearer ? ref : near_ref;
+            }
+        }
+        bx += RT_LIST_BOX_FLOATS;
+        by += RT_LIST_BOX_FLOATS;
+        bz += RT_LIST_BOX_FLOATS;
+    }
+    tv.cur = near_ref; // kDone when no box is hit (nothing was pushed then)
 }
 
 // one leaf step (tv.cur is a leaf reference): binary64 primitive test, then pop

@@ -10,6 +10,8 @@
 #define RT_TILE_PIXELS 64
 #define RT_STACK_DEPTH 24   /* traversal stack entries per lane; the builder bounds the tree depth to this */
 #define RT_MAX_HOISTED 4    /* scene-filling prims tested up front instead of through the BVH */
+#define RT_LIST_MAX 24      /* general scenes of up to this many BVH leaves are walked as a box LIST (rtl::trav_list_step) */
+#define RT_LIST_BOX_FLOATS 9 /* one list box: {lo, hi, lo} per axis -- entry plane at [s], exit plane at [s + 1], s = sign bit of 1/d */
 #define RT_MAX_CHAIN 4      /* transform levels above one leaf (Sprite > BVH > Sprite > TransformedGeometry ...) */
 #define RT_JOB_SPP_MAX 32   /* samples per pixel in one job at most (job = one 8x8 tile x job_spp samples) */
 #define RT_NO_MATERIAL 0xFFFFFFFFu
@@ -140,7 +142,8 @@ struct RtLaunch {
     const RtMaterial *materials;
     const RtTexture *textures;
     const uint8_t *image_blob;
-    int32_t n_nodes;
+    int32_t n_nodes;       // RtNode records behind `nodes` (in list mode: the packed box list, rounded up to whole records)
+    int32_t n_list;        // 0: BVH walk.  > 0: `nodes` holds this many list boxes (RT_LIST_BOX_FLOATS binary32 each), leaf i = prim n_hoisted + i
     int32_t stack_entries; // LDS stack entries per lane for this scene (tree depth + 1, <= RT_STACK_DEPTH)
     int32_t swap_cap;      // entries per class queue of the swap-at-shade queues (rt_kernels.hip)
     uint32_t root;      // reference of the BVH root in the scene's form, or its kDone when every prim is hoisted

@@ -96,6 +96,7 @@ pub struct rt_scene_info {
     pub material_bytes: c_int,
     pub feature_mask: c_uint,
     pub device_bytes: usize,
+    pub n_list: c_int,
 }
 
 pub const RT_OK: c_int = 0;

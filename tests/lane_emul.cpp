@@ -49,8 +49,13 @@ void run(const RtLaunch &L, int x0, int y0, int x1, int y1, double *out, double 
                     rtl::begin_segment<G, M, T>(L, &ps, tv, st, &cnt[3]);
                     while (tv.cur != R::kDone) {
                         if (tv.cur < R::kLeaf) {
-                            cnt[2]++;
-                            rtl::trav_node_step(L.nodes, tv, st);
+                            if (L.n_list) {
+                                cnt[2] += (unsigned long long)L.n_list;
+                                rtl::trav_list_step(reinterpret_cast<const float *>(L.nodes), (uint32_t)L.n_list, (uint32_t)L.n_hoisted, tv, st);
+                            } else {
+                                cnt[2]++;
+                                rtl::trav_node_step(L.nodes, tv, st);
+                            }
                         } else {
                             rtl::leaf_step<G, M, T>(L, &ps, tv, st, &cnt[3]);
                         }
@@ -91,6 +96,8 @@ extern "C" int lane_emul_render(rt_scene *s, const rt_camera *cam, int W, int H,
     L.textures = s->flat.textures.data();
     L.image_blob = s->flat.image_blob.data();
     L.root = s->flat.root;
+    L.n_list = s->flat.n_list;
+    L.n_nodes = (int)s->flat.nodes.size();
     L.n_hoisted = s->flat.n_hoisted;
     L.n_prims = s->flat.n_leaf_prims;
     for (int i = 0; i < 3; ++i) {

@@ -311,6 +311,23 @@ def test_media_over_open_boundaries_match_oracle(rt, scenes, oracle, gpu_device)
     _close(img, oracle.build_oracle(d, bvh_seed=11).render(128, 96, 16, 40, seed=5, iterative=True, nthreads=8), max_bad=4)
 
 
+def test_list_walk_equals_tree_walk_on_the_gpu(rt, scenes, oracle, gpu_device, monkeypatch):
+    """the Cornell box through the box-list kernels (rt_scene_info.n_list = 18) and, with RT_NO_LIST=1, through the tree
+    walk: identical images, both equal to the oracle; the list looks at 18 boxes per segment"""
+    d = scenes.cornell(1.0)
+    sc, cam = scenes.build_product(d, device=gpu_device)
+    assert sc.info()["n_list"] == 18
+    img, c = sc.render(cam, 200, 200, 16, 100, seed=4, counters=True)
+    assert c["nodes_visited"] == 18 * c["segments"]
+    monkeypatch.setenv("RT_NO_LIST", "1")
+    sc2, cam2 = scenes.build_product(d, device=gpu_device)
+    assert sc2.info()["n_list"] == 0
+    img2, c2 = sc2.render(cam2, 200, 200, 16, 100, seed=4, counters=True)
+    assert np.array_equal(img, img2) and c["segments"] == c2["segments"] and c["samples"] == c2["samples"]
+    assert np.array_equal(img, sc.render(cam, 200, 200, 16, 100, seed=4))  # the timed (non-counting) build
+    _close(img, oracle.build_oracle(d).render(200, 200, 16, 100, seed=4, iterative=True, nthreads=8), max_bad=0)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_scenes_match_oracle(rt, scenes, oracle, gpu_device, seed):
     """Random transforms (incl. non-rigid), cubes, media, textures, lens: general kernel vs oracle."""

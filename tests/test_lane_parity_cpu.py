@@ -174,6 +174,38 @@ def test_media_over_open_boundaries_exact(scenes, oracle, lane_emul):
     assert cnt["segments"] == ocnt["segments"] > 64 * 48 * 8 * 1.1  # the fog in front of the rectangle scatters
 
 
+def test_list_walk_equals_tree_walk(scenes, oracle, lane_emul, monkeypatch):
+    """General scenes of up to RT_LIST_MAX leaves are walked as a box list (rtl::trav_list_step) -- the Cornell box is one.
+    Same boxes, same binary64 tests, same tie rule: the image equals the tree walk's and the oracle's bit for bit."""
+    d = scenes.cornell(1.0)
+    sc, cam = scenes.build_product(d, device=-1)
+    info = sc.info()
+    assert info["n_list"] == 18 == info["n_prims"] and info["n_nodes"] == 17 and info["node_bytes"] == 36
+    img, cnt, high = lane_emul.render(sc, cam, 48, 48, 4, 60, 9)
+    assert high <= info["n_list"] - 1
+    assert cnt["nodes_visited"] == cnt["segments"] * 18  # every segment looks at every box once
+    monkeypatch.setenv("RT_NO_LIST", "1")
+    sc2, cam2 = scenes.build_product(d, device=-1)
+    assert sc2.info()["n_list"] == 0 and sc2.info()["node_bytes"] == 64
+    img2, cnt2, _ = lane_emul.render(sc2, cam2, 48, 48, 4, 60, 9)
+    assert np.array_equal(img, img2) and cnt["segments"] == cnt2["segments"]
+    assert np.array_equal(img, oracle.build_oracle(d).render(48, 48, 4, 60, 9, iterative=True, nthreads=8))
+    monkeypatch.delenv("RT_NO_LIST")
+    # spheres-only scenes keep the tree however small; 25 general leaves are one too many for the list
+    few = scenes.SceneDesc()
+    for k in range(5):
+        few.sprite(few.geom("sphere", 0.5), few.lambertian_rgb((0.5, 0.5, 0.5)), scenes.mat4_translation((k, 0.0, 5.0)))
+    few.camera = d.camera
+    assert scenes.build_product(few, device=-1)[0].info()["n_list"] == 0
+    for n, want in ((24, 24), (25, 0)):
+        many = scenes.SceneDesc()
+        for k in range(n):
+            many.sprite(many.geom("rectangle", 1.0, 1.0), many.lambertian_rgb((0.5, 0.5, 0.5)),
+                        scenes.mat4_multiplied(scenes.mat4_translation((k % 5, k // 5, 5.0)), scenes.mat4_rotation(0.3, (0.0, 1.0, 0.0))))
+        many.camera = d.camera
+        assert scenes.build_product(many, device=-1)[0].info()["n_list"] == want
+
+
 def rt_feat(scenes, name):
     import sys
     return getattr(sys.modules["ray_tracer_amd"], name)
