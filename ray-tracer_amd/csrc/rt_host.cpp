@@ -578,6 +578,7 @@ struct Flattener {
                 lf.geo.g[2] = chain[0].M[14];
                 lf.geo.g[3] = b.p[0];
                 lf.extra.e[0] = g.p[0];
+                lf.extra.e[1] = -1.0 / g.p[0]; // (-1.0 / self.density), src/volume.rs:62,84
                 lf.bound = chain_bound(sphere_bound(b.p[0]), chain, {});
             } else {
                 lf.meta.kind = RT_PRIM_MEDIUM_C;

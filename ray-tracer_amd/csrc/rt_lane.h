@@ -233,39 +233,65 @@ RT_HD void to_world(const RtXform &x, Rec *r) {
 }
 
 // ---- ConstantMedium<Sphere>::hit, boundary frame (src/volume.rs:46-100) ----
-RT_HD bool medium_hit(V3 oc, V3 d, double radius, double density, uint64_t rng_base, uint32_t segment, uint32_t slot,
+// neg_inv_density = (-1.0 / density), the reference's own first factor (volume.rs:62,84), divided once on the host.
+// RECORD = false (traversal: only t is used): the reference decides "entering or leaving" by the sign of
+// record1.normal . direction with normal = normalized(p / r) -- six divisions and a square root for one sign.  That dot
+// product equals c * sum_i p_i d_i (1 + theta_i) with c = 1 / (r |p / r|) > 0 and |theta_i| < 8 * 2^-53 (one rounding each
+// in p_i / r, the length, q_i / length, the product, two sums), so whenever |fl(sum p_i d_i)| > 1e-12 * sum |p_i d_i| (and
+// nothing is near the ends of the exponent range) its sign is the sign of the plain sum; only the remaining, grazing
+// cases evaluate the reference's expression.  The record (RECORD = true) always does.
+template <bool RECORD>
+RT_HD bool medium_hit(V3 oc, V3 d, double radius, double neg_inv_density, uint64_t rng_base, uint32_t segment, uint32_t slot,
                       unsigned long long *draws, bool uv, Rec *r) {
     double a = dot(d, d);
     double t1;
     if (!sphere_t(oc, d, a, radius, &t1)) return false;
     Rec r1;
-    sphere_finish(oc, d, radius, t1, uv, &r1);
-    if (dot(r1.n, d) < 0.0) {
+    bool entering;
+    bool sure = false;
+    if (!RECORD) {
+        r1.t = t1;
+        r1.p = oc + d * t1; // sphere_finish's p
+        const double x = r1.p.x * d.x, y = r1.p.y * d.y, z = r1.p.z * d.z;
+        const double s = x + y + z, mag = fabs(x) + fabs(y) + fabs(z);
+        sure = radius > 1e-100 && radius < 1e100 && mag > 1e-150 && mag < 1e150 && fabs(s) > 1e-12 * mag;
+        entering = s < 0.0;
+    }
+    if (!sure) {
+        sphere_finish(oc, d, radius, t1, uv, &r1);
+        entering = dot(r1.n, d) < 0.0;
+    }
+    if (entering) {
         V3 o2 = r1.p + d * 1e-6; // restarted ray
         double t2;
         if (!sphere_t(o2, d, a, radius, &t2)) return false;
         Rec r2;
-        sphere_finish(o2, d, radius, t2, uv, &r2);
+        r2.t = t2;
+        if (RECORD) sphere_finish(o2, d, radius, t2, uv, &r2);
         double inside = r2.t;
         ++*draws;
-        double distance = (-1.0 / density) * log_cold(rt_u64_to_range01(rt_rng_keyed_from_base(rng_base, segment, slot)));
+        double distance = neg_inv_density * log_cold(rt_u64_to_range01(rt_rng_keyed_from_base(rng_base, segment, slot)));
         if (distance > inside) return false;
-        r->u = r1.u + r2.u;
-        r->v = r1.v + r2.v;
         r->t = r1.t + distance;
-        r->p = o2 + d * (r1.t + distance); // on the restarted ray (quirk Q9)
-        r->n = (r1.n + r2.n) / 2.0;
+        if (RECORD) {
+            r->u = r1.u + r2.u;
+            r->v = r1.v + r2.v;
+            r->p = o2 + d * (r1.t + distance); // on the restarted ray (quirk Q9)
+            r->n = (r1.n + r2.n) / 2.0;
+        }
         return true;
     }
     double inside = r1.t;
     ++*draws;
-    double distance = (-1.0 / density) * log_cold(rt_u64_to_range01(rt_rng_keyed_from_base(rng_base, segment, slot)));
+    double distance = neg_inv_density * log_cold(rt_u64_to_range01(rt_rng_keyed_from_base(rng_base, segment, slot)));
     if (distance > inside) return false;
-    r->u = r1.u;
-    r->v = r1.v;
     r->t = distance;
-    r->p = oc + d * distance;
-    r->n = r1.n;
+    if (RECORD) {
+        r->u = r1.u;
+        r->v = r1.v;
+        r->p = oc + d * distance;
+        r->n = r1.n;
+    }
     return true;
 }
 
@@ -416,7 +442,7 @@ RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx
         const RtPrimMeta &P = L.prim_meta[pi];
         if (MEDIUM && kind == RT_PRIM_MEDIUM_T) {
             V3 c = mk(G.g[0], G.g[1], G.g[2]);
-            if (!medium_hit(o - c, d, G.g[3], L.prim_extra[pi].e[0], sc.rng_base, sc.segment, P.aux, &sc.draws, uv, r)) return false;
+            if (!medium_hit<RECORD>(o - c, d, G.g[3], L.prim_extra[pi].e[1], sc.rng_base, sc.segment, P.aux, &sc.draws, uv, r)) return false;
             if (RECORD) r->p = r->p + c;
             return true;
         }

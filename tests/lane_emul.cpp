@@ -169,3 +169,20 @@ extern "C" int lane_emul_ball_check(uint64_t seed, uint64_t stream, int max_iter
     bounded_state[0] = b.s0, bounded_state[1] = b.s1, bounded_state[2] = b.draws;
     return calls;
 }
+
+// ConstantMedium<Sphere>::hit in its traversal form (sign of normal . direction from the plain sum p . d, rt_lane.h
+// medium_hit<false>) against the record form (the reference's normalized(p / r) . d): same hit / miss, same t.
+// out = {hit_traversal, t_traversal, hit_record, t_record}
+extern "C" void lane_emul_medium_forms(const double oc[3], const double d[3], double radius, double density, uint64_t base,
+                                       uint32_t segment, uint32_t slot, double out[4]) {
+    const rtl::V3 o = rtl::mk(oc[0], oc[1], oc[2]), dir = rtl::mk(d[0], d[1], d[2]);
+    unsigned long long draws = 0;
+    rtl::Rec a, b;
+    a.t = b.t = 0.0;
+    const bool ha = rtl::medium_hit<false>(o, dir, radius, -1.0 / density, base, segment, slot, &draws, false, &a);
+    const bool hb = rtl::medium_hit<true>(o, dir, radius, -1.0 / density, base, segment, slot, &draws, false, &b);
+    out[0] = ha ? 1.0 : 0.0;
+    out[1] = ha ? a.t : 0.0;
+    out[2] = hb ? 1.0 : 0.0;
+    out[3] = hb ? b.t : 0.0;
+}

@@ -40,3 +40,14 @@ def ball_check(seed, stream, max_iter):
     a, b = (C.c_uint64 * 3)(), (C.c_uint64 * 3)()
     calls = _LIB.lane_emul_ball_check(seed, stream, max_iter, p.ctypes.data_as(_DP), q.ctypes.data_as(_DP), a, b)
     return calls, p, q, tuple(int(v) for v in a), tuple(int(v) for v in b)
+
+
+_LIB.lane_emul_medium_forms.restype = None
+_LIB.lane_emul_medium_forms.argtypes = [_DP, _DP, C.c_double, C.c_double, C.c_uint64, C.c_uint32, C.c_uint32, _DP]
+
+
+def medium_forms(oc, d, radius, density, base=12345, segment=0, slot=0):
+    """-> ((hit, t) of the traversal form, (hit, t) of the record form) of ConstantMedium<Sphere>::hit."""
+    oc, d, out = np.ascontiguousarray(oc, dtype=np.float64), np.ascontiguousarray(d, dtype=np.float64), np.zeros(4)
+    _LIB.lane_emul_medium_forms(oc.ctypes.data_as(_DP), d.ctypes.data_as(_DP), radius, density, base, segment, slot, out.ctypes.data_as(_DP))
+    return (bool(out[0]), float(out[1])), (bool(out[2]), float(out[3]))

@@ -206,6 +206,41 @@ def test_list_walk_equals_tree_walk(scenes, oracle, lane_emul, monkeypatch):
         assert scenes.build_product(many, device=-1)[0].info()["n_list"] == want
 
 
+def test_medium_traversal_form_equals_record_form(lane_emul):
+    """medium_hit<false> takes the sign of normal . direction from the plain sum p . d when that sum is clearly non-zero
+    and falls back to the reference's normalized(p / r) . d otherwise: hit / miss and t must equal the record form's on
+    ordinary rays, on rays that graze the boundary (where the fallback runs) and at extreme scales."""
+    rng = np.random.default_rng(3)
+    n_hit = n_graze = 0
+    for i in range(20000):
+        r = float(10.0 ** rng.uniform(-3, 3)) if i % 3 else float(rng.uniform(0.5, 2.0))
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        if i % 4 == 0:  # grazing: a ray tangent to the sphere, nudged in or out by ulps .. 1e-9
+            q = np.cross(d, rng.normal(size=3))
+            q /= np.linalg.norm(q)
+            oc = q * r * (1.0 + float(rng.choice([-1, 1])) * float(10.0 ** rng.uniform(-16, -9))) - d * r * float(rng.uniform(0.0, 3.0))
+            n_graze += 1
+        elif i % 4 == 1:  # origin inside
+            oc = rng.normal(size=3)
+            oc *= r * float(rng.uniform(0.0, 0.999)) / np.linalg.norm(oc)
+        else:
+            oc = rng.normal(size=3) * r * 2.0
+        if i % 7 == 0:
+            d = d * float(10.0 ** rng.uniform(-3, 3))  # un-normalised directions (quirk Q5: sprites do not renormalise)
+        a, b = lane_emul.medium_forms(oc, d, r, float(10.0 ** rng.uniform(-3, 1)), base=int(rng.integers(1 << 62)), segment=i % 50, slot=i % 7)
+        assert a == b, (i, oc, d, r, a, b)
+        n_hit += a[0]
+    assert n_hit > 1500 and n_graze == 5000
+    # scales at which the shortcut declines (guards on radius and on |p . d|): still the same answers
+    for r, scale in ((1e-120, 1e-120), (1e120, 1e120), (1.0, 1e-160), (1.0, 1e160)):
+        for k in range(50):
+            d = rng.normal(size=3) * (scale if r == 1.0 else 1.0)
+            oc = rng.normal(size=3) * r * 0.5
+            a, b = lane_emul.medium_forms(oc, d, r, 0.5 / max(r, 1e-300) if r != 1.0 else 0.5, base=k)
+            assert a == b
+
+
 def rt_feat(scenes, name):
     import sys
     return getattr(sys.modules["ray_tracer_amd"], name)
