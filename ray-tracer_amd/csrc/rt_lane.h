@@ -154,11 +154,10 @@ RT_HD bool sphere_t(V3 oc, V3 d, double a, double radius, double *t_out) {
     double sq = sqrt(disc);
     double t1 = (-b - sq) / (2.0 * a);
     double t2 = (-b + sq) / (2.0 * a);
-    if (!(t1 < t2)) {
-        double tmp = t1;
-        t1 = t2;
-        t2 = tmp;
-    }
+    // The reference orders the roots here (`if t1 < t2 { (t1, t2) } else { (t2, t1) }`).  That never changes the outcome:
+    // sq >= 0 (or -0, NaN) and 2a >= 0 (a sum of squares), so -b - sq <= -b + sq and t1 <= t2 by the monotonicity of
+    // rounding; the swap fires only for equal roots or when one is NaN, and then "the first root above 1e-6, else the
+    // second" picks the same value from either order (a NaN is never > 1e-6, zeros of either sign neither).
     double t;
     if (t1 > RTL_EPS)
         t = t1;
