@@ -308,6 +308,10 @@ def main():
             "prims_per_sample": cnt["prims_tested"] / ns, "simd_utilisation": util, "lane_utilisation_cycle_weighted": lane_util,
             "block_executions_per_sample": {b: cnt[b + "_wave"] * 64 / ns for b in ("node", "leaf", "shade")},
             "block_cycle_share": cyc,
+            "counters_note": "simd_utilisation, block_executions, block_cycle_share and swap_at_shade come from the COUNTING instantiation "
+                             "of the same kernel on this image at min(spp, 64) spp: wall-clock shares by s_memtime, and that build keeps "
+                             "76-176 bytes of scratch per lane at the same VGPR budget (ray-tracer_amd/csrc/_obj/resource_usage.txt); "
+                             "instruction-level figures (issue roofline, lane utilisation by PMC) are rocprofv3's on the timed build",
             "swap_at_shade": ({k[5:]: cnt[k] for k in cnt if k.startswith("swap_")} if cnt.get("swap_scattered") else None)})
         cfg_name = BASELINE_CONFIGS.get((a.scene, W, H, spp))
         scene_words = {"book_one": "book-one random-spheres", "cornell": "cornell-box", "cover": "book-two cover (main.rs)"}[a.scene]

@@ -733,6 +733,26 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
             lf.meta.xform = push_chain(fs, lf.chain);
             fl.finish_meta(&lf.meta, lf.chain);
         }
+        if ((lf.meta.kind & 0xFFu) == RT_PRIM_RECT_C) {
+            // the record's normal: Rectangle::hit's (0, 0, 1) (src/geometry.rs:176) carried up the chain as the kernel's
+            // chain_up does it -- innermost level first, M (not M^-T, quirk Q5) row by row in Vec4::transformed's order
+            // (src/vec4.rs:78-91) with w = 0, a pure-translation level leaving it alone.  A constant of the leaf.
+            double n[3] = {0.0, 0.0, 1.0};
+            for (size_t k = lf.chain.size(); k-- > 0;) {
+                const Link &l = lf.chain[k];
+                if (l.translation) continue;
+                RtXform x;
+                make_xform(l.M, l.Minv, &x);
+                const double *m = x.m;
+                const double a = m[0] * n[0] + m[1] * n[1] + m[2] * n[2] + m[3] * 0.0;
+                const double b = m[4] * n[0] + m[5] * n[1] + m[6] * n[2] + m[7] * 0.0;
+                const double c = m[8] * n[0] + m[9] * n[1] + m[10] * n[2] + m[11] * 0.0;
+                n[0] = a, n[1] = b, n[2] = c;
+            }
+            lf.geo.g[2] = n[0];
+            lf.geo.g[3] = n[1];
+            lf.extra.e[0] = n[2];
+        }
         fs.prim_meta.push_back(lf.meta);
         fs.prim_geo.push_back(lf.geo);
         fs.prim_extra.push_back(lf.extra);

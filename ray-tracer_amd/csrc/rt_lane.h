@@ -337,6 +337,21 @@ RT_HD void chain_up(const RtLaunch &L, uint32_t first, uint32_t len, uint32_t tm
     }
 }
 
+RT_HD void chain_up_point(const RtLaunch &L, uint32_t first, uint32_t len, uint32_t tmask, V3 *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t k = 0; k < (uint32_t)RT_MAX_CHAIN; ++k) {
+        const uint32_t i = (uint32_t)RT_MAX_CHAIN - 1u - k;
+        if (i >= len) continue;
+        const RtXform &X = L.xforms[first + i];
+        if ((tmask >> i) & 1u)
+            *p = mk(p->x + X.m[3], p->y + X.m[7], p->z + X.m[11]);
+        else
+            *p = xf_point(X.m, *p);
+    }
+}
+
 // sphere / rectangle in its own frame.  RECORD = false: only r->t is meaningful
 template <bool RECORD>
 RT_HD bool shape_hit(uint32_t kind, const RtPrimGeo &G, V3 lo, V3 ld, bool uv, Rec *r) {
@@ -458,6 +473,45 @@ RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx
         return true;
     }
     return false;
+}
+
+// The hit record of primitive `pi` at the parameter t the traversal found (shading).  The same arithmetic as the full test
+// -- which would only compute the same t again from the same operands (two divisions and a square root for a sphere, a
+// division for a rectangle) and re-check bounds that are known to hold.  A rectangle's world normal is a constant of the
+// leaf: the chain applied to (0, 0, 1), evaluated once at commit by the same expressions (rt_host.cpp, leaf_normal) and kept
+// in geo.g[2], geo.g[3], extra.e[0].  Media go through the full test (keyed draw, both boundary hits).
+template <bool GENERAL, int MEDIUM>
+RT_HD void prim_record(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double t, SegCtx &sc, Rec *r) {
+    const RtPrimGeo &G = L.prim_geo[pi];
+    uint32_t kw = (uint32_t)RT_PRIM_SPHERE_T;
+    if (GENERAL || MEDIUM) kw = L.prim_meta[pi].kind;
+    const uint32_t kind = kw & 0xFFu;
+    if (kind == RT_PRIM_SPHERE_T) {
+        const V3 c = mk(G.g[0], G.g[1], G.g[2]);
+        sphere_finish(o - c, d, G.g[3], t, false, r);
+        r->p = r->p + c;
+        return;
+    }
+    if (GENERAL || MEDIUM) {
+        if (kind == RT_PRIM_MEDIUM_T || kind == RT_PRIM_MEDIUM_C) {
+            prim_hit<GENERAL, MEDIUM, true>(L, pi, o, d, dot(d, d), sc, r, false);
+            return;
+        }
+        const uint32_t first = L.prim_meta[pi].xform, len = (kw >> RT_META_CHAIN_SHIFT) & 7u, tmask = (kw >> RT_META_TMASK_SHIFT) & 0xFu;
+        V3 lo = o, ld = d;
+        chain_down(L, first, len, tmask, &lo, &ld);
+        if (kind == RT_PRIM_SPHERE_C) {
+            sphere_finish(lo, ld, G.g[0], t, false, r);
+            chain_up(L, first, len, tmask, r);
+        } else { // RT_PRIM_RECT_C: rect_hit's t, p (src/geometry.rs:160,176), the chain for the point, the leaf's normal
+            r->t = t;
+            r->u = 0.0;
+            r->v = 0.0;
+            r->p = lo + ld * t;
+            chain_up_point(L, first, len, tmask, &r->p);
+            r->n = mk(G.g[2], G.g[3], L.prim_extra[pi].e[0]);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- traversal
@@ -908,7 +962,7 @@ RT_HD bool finish_segment(const RtLaunch &L, PathState *ps, const Trav &tv, V3 *
     Rec rec;
     if (GENERAL || MEDIUM) {
         // rebuild the record of the winner (same arithmetic, same t, same keyed draws)
-        prim_hit<GENERAL, MEDIUM, true>(L, prim, ps->o, ps->d, dot(ps->d, ps->d), sc, &rec, false);
+        prim_record<GENERAL, MEDIUM>(L, prim, ps->o, ps->d, tv.best_t, sc, &rec);
     } else {
         const RtPrimGeo &G = L.prim_geo[prim];
         V3 c = mk(G.g[0], G.g[1], G.g[2]);
