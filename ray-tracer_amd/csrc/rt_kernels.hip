@@ -41,6 +41,15 @@
 #include "rt_lane.h"
 #include "rt_types.h"
 
+// The library is built from TWO compilations of this file (Makefile): part 1 holds the spheres-only and the lean general
+// families plus the small kernels and every extern "C" entry; part 2 holds the families with media / textures, which sit
+// at their register limit and are compiled with the ordinary Vec3 division (-DRT_PLAIN_DIV3: the shared-reciprocal form of
+// rt_lane.h costs them 32-48 bytes of scratch per lane, +1 % on the book-two cover, where it gains 2 % elsewhere).
+// RT_TU_PART 0 = everything in one object (not used by the Makefile).
+#ifndef RT_TU_PART
+#define RT_TU_PART 0
+#endif
+
 #ifndef RT_BLOCK
 #define RT_BLOCK 512 /* threads per workgroup: 8 waves share one LDS copy of the node array */
 #endif
@@ -684,6 +693,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
     }
 }
 
+#if RT_TU_PART != 2
 // Sum this pass's samples in sample order on top of the running sums; the last
 // pass divides by spp (`pixel /= subPixelSampleCount`, examples/book-one.rs:76).
 // One thread per owned pixel; consecutive threads read consecutive 32-byte records.
@@ -747,6 +757,8 @@ __global__ void probe_math_kernel(const double *a, const double *b, int n, doubl
     out_div[i] = a[i] / b[i];
 }
 
+#endif // RT_TU_PART != 2
+
 // ---- dispatch over the template instantiations ----
 typedef void (*KernelFn)(const RtLaunch);
 
@@ -770,26 +782,48 @@ KernelFn pick3(bool lens, bool count, bool ldsnodes) {
 }
 // lds_mode: bit 0 = node array copied to LDS, bit 1 = swap-at-shade queues, bit 2 = 32-bit references (general families),
 // bit 3 = box list instead of the tree (general families, 16-bit references, always in LDS)
-KernelFn pick(unsigned features, bool lens, bool count, int lds_mode) {
+#if RT_TU_PART != 1
+// the families with media / textures (feature bits 2, 4, 8)
+KernelFn pick_media(unsigned features, bool lens, bool count, int lds_mode) {
     const bool ldsnodes = (lds_mode & 1) != 0, swap = (lds_mode & 2) != 0, wide = (lds_mode & 4) != 0, list = (lds_mode & 8) != 0;
     if (list) {
-        if (features == 1u) return swap ? pick3<true, 0, false, true, false, true>(lens, count, true) : pick3<true, 0, false, false, false, true>(lens, count, true);
         if (features & 8u) return swap ? pick3<true, 2, true, true, false, true>(lens, count, true) : pick3<true, 2, true, false, false, true>(lens, count, true);
         return swap ? pick3<true, 1, true, true, false, true>(lens, count, true) : pick3<true, 1, true, false, false, true>(lens, count, true);
     }
     if (wide) { // more than 32767 prims or nodes: the node array never fits LDS
-        if ((features & ~1u) == 0u) return swap ? pick3<true, 0, false, true, true>(lens, count, false) : pick3<true, 0, false, false, true>(lens, count, false);
         if (features & 8u) return swap ? pick3<true, 2, true, true, true>(lens, count, false) : pick3<true, 2, true, false, true>(lens, count, false);
         return swap ? pick3<true, 1, true, true, true>(lens, count, false) : pick3<true, 1, true, false, true>(lens, count, false);
     }
-    // general prims only (matrices, rectangles, cubes: the Cornell box): no medium / texture code in the kernel
-    if (features == 1u) return swap ? pick3<true, 0, false, true>(lens, count, ldsnodes) : pick3<true, 0, false, false>(lens, count, ldsnodes);
     // media over a general boundary (bit 8): the kernel with medium_general_hit; else the one with sphere media only
     if (features & 8u) return swap ? pick3<true, 2, true, true>(lens, count, ldsnodes) : pick3<true, 2, true, false>(lens, count, ldsnodes);
-    if (features != 0u) return swap ? pick3<true, 1, true, true>(lens, count, ldsnodes) : pick3<true, 1, true, false>(lens, count, ldsnodes);
+    return swap ? pick3<true, 1, true, true>(lens, count, ldsnodes) : pick3<true, 1, true, false>(lens, count, ldsnodes);
+}
+#endif
+} // namespace
+#if RT_TU_PART == 2
+extern "C" void *rt_pick_media_kernel(unsigned features, int lens, int count, int lds_mode) {
+    return (void *)pick_media(features, lens != 0, count != 0, lds_mode);
+}
+#elif RT_TU_PART == 1
+extern "C" void *rt_pick_media_kernel(unsigned features, int lens, int count, int lds_mode);
+#endif
+#if RT_TU_PART != 2
+namespace {
+KernelFn pick(unsigned features, bool lens, bool count, int lds_mode) {
+    const bool ldsnodes = (lds_mode & 1) != 0, swap = (lds_mode & 2) != 0, wide = (lds_mode & 4) != 0, list = (lds_mode & 8) != 0;
+    if ((features & ~1u) != 0u) {
+#if RT_TU_PART == 1
+        return (KernelFn)rt_pick_media_kernel(features, lens, count, lds_mode);
+#else
+        return pick_media(features, lens, count, lds_mode);
+#endif
+    }
+    // general prims only (matrices, rectangles, cubes: the Cornell box): no medium / texture code in the kernel
+    if (list) return swap ? pick3<true, 0, false, true, false, true>(lens, count, true) : pick3<true, 0, false, false, false, true>(lens, count, true);
+    if (wide) return swap ? pick3<true, 0, false, true, true>(lens, count, false) : pick3<true, 0, false, false, true>(lens, count, false);
+    if (features == 1u) return swap ? pick3<true, 0, false, true>(lens, count, ldsnodes) : pick3<true, 0, false, false>(lens, count, ldsnodes);
     return swap ? pick3<false, 0, false, true>(lens, count, ldsnodes) : pick3<false, 0, false, false>(lens, count, ldsnodes);
 }
-
 } // namespace
 
 extern "C" int rt_kernel_block_size(unsigned features);
@@ -867,4 +901,4 @@ extern "C" int rt_launch_probe_math(const double *a, const double *b, int n, dou
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
-
+#endif // RT_TU_PART != 2

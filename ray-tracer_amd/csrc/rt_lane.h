@@ -42,7 +42,36 @@ RT_HD V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 RT_HD V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
 RT_HD V3 operator*(V3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
 RT_HD V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+// Vec3 / f64 (src/vec3.rs:221-231): three quotients by ONE denominator.  The compiler's binary64 division is div_scale x 2,
+// v_rcp_f64, two Newton steps on the reciprocal (4 fma), q = a * r, e = fma(-b, q, a), div_fmas(e, r, q), div_fixup -- and
+// for operands in the middle of the exponent range div_scale scales nothing, div_fmas is a plain fma and div_fixup returns
+// its argument.  The refined reciprocal then depends on the denominator alone: it is computed once and each component costs
+// mul + fma + fma with exactly the instructions and operands the full expansion would use (same bits by construction; the
+// quotients stay correctly rounded, tests/test_gpu_parity.py::test_device_sqrt_div_correctly_rounded and every bit-exact
+// image test).  Operands outside [2^-500, 2^256] in magnitude (zero, denormal, huge) take the ordinary division.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_PLAIN_DIV3)
+// (out of line: inlined at every division site, the ordinary divisions cost registers the hot path needs)
+static __device__ __attribute__((noinline)) V3 div3_ordinary(V3 a, double s) { return mk(a.x / s, a.y / s, a.z / s); }
+RT_HD V3 operator/(V3 a, double s) {
+    // every operand's biased exponent in [523, 1279]: the three numerators through their min / max
+    const uint32_t ex = (uint32_t)__double2hiint(a.x) & 0x7FF00000u, ey = (uint32_t)__double2hiint(a.y) & 0x7FF00000u,
+                   ez = (uint32_t)__double2hiint(a.z) & 0x7FF00000u, es = (uint32_t)__double2hiint(s) & 0x7FF00000u;
+    const uint32_t lo = min(min(ex, ey), min(ez, es)), hi = max(max(ex, ey), max(ez, es));
+    if (lo >= 0x20B00000u && hi <= 0x4FF00000u) {
+        const double ns = -s;
+        const double r0 = __builtin_amdgcn_rcp(s);
+        const double f0 = fma(ns, r0, 1.0);
+        const double r1 = fma(r0, f0, r0);
+        const double f1 = fma(ns, r1, 1.0);
+        const double r = fma(r1, f1, r1);
+        const double qx = a.x * r, qy = a.y * r, qz = a.z * r;
+        return mk(fma(fma(ns, qx, a.x), r, qx), fma(fma(ns, qy, a.y), r, qy), fma(fma(ns, qz, a.z), r, qz));
+    }
+    return div3_ordinary(a, s);
+}
+#else
 RT_HD V3 operator/(V3 a, double s) { return mk(a.x / s, a.y / s, a.z / s); }
+#endif
 RT_HD V3 adds(V3 a, double s) { return mk(a.x + s, a.y + s, a.z + s); } // Add<f64>, src/vec3.rs:153-163
 RT_HD V3 subs(V3 a, double s) { return mk(a.x - s, a.y - s, a.z - s); } // Sub<f64>, src/vec3.rs:185-195
 RT_HD double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }          // src/vec3.rs:76-78
