@@ -290,6 +290,7 @@ static void fill_launch(const rt_scene *s, const rt_camera *cam, const rt_render
     L->stack_entries = s->flat.n_list ? s->flat.n_list - 1 : std::min(RT_STACK_DEPTH, s->flat.max_depth + 1);
     L->root = s->flat.root;
     L->n_hoisted = s->flat.n_hoisted;
+    L->world_mid = s->flat.world_mid ? 1 : 0;
     L->n_prims = s->flat.n_leaf_prims;
     for (int i = 0; i < 3; ++i) {
         L->cam.eye[i] = cam->eye[i];

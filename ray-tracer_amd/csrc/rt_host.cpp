@@ -753,6 +753,9 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
             lf.geo.g[3] = n[1];
             lf.extra.e[0] = n[2];
         }
+        if ((lf.meta.kind & 0xFFu) == RT_PRIM_SPHERE_T || (lf.meta.kind & 0xFFu) == RT_PRIM_MEDIUM_T)
+            for (int c = 0; c < 4; ++c)
+                if (!(std::fabs(lf.geo.g[c]) <= 0x1p100)) fs.world_mid = false; // (NaN included)
         fs.prim_meta.push_back(lf.meta);
         fs.prim_geo.push_back(lf.geo);
         fs.prim_extra.push_back(lf.extra);

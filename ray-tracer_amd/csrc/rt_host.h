@@ -73,6 +73,7 @@ struct FlatScene {
     std::vector<uint8_t> image_blob;
     uint32_t root = RT_CUR_DONE; // reference (RT_REF_*) or RT_CUR_DONE if the BVH is empty
     bool wide = false;           // 32-bit references (more than 32767 prims or nodes)
+    bool world_mid = true;       // every world-space sphere's centre and radius are <= 2^100 in magnitude (rtl::world_roots_rcp)
     int n_list = 0;              // > 0: `nodes` holds the box list of the n_list BVH leaves instead of the tree (small general scenes)
     int n_leaf_prims = 0;
     int max_depth = 0;

@@ -173,16 +173,91 @@ RT_HD void camera_ray(const RtCameraD &c, double u, double v, Rng &g, V3 *o, V3 
     }
 }
 
+// The two roots (-b -+ sqrt(disc)) / (2 a) of Sphere::hit share their denominator: one refined reciprocal as in Vec3 / f64
+// above, when 2a lies in [2^-100, 2^100] and neither numerator exceeds 2^256.  A numerator below 2^-500 (zero, denormal,
+// cancellation dust) may then come out with other low bits than the ordinary division's, but both are below 2^-300 in
+// magnitude and a root only ever reaches `> 1e-6` tests before it is used: the same roots are rejected either way.
+struct Roots {
+    double t1, t2;
+};
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_PLAIN_DIV3)
+static __device__ __attribute__((noinline)) Roots roots_ordinary(double n1, double n2, double den) {
+    Roots r;
+    r.t1 = n1 / den;
+    r.t2 = n2 / den;
+    return r;
+}
+RT_HD Roots sphere_roots(double n1, double n2, double den) {
+    const uint32_t e1 = (uint32_t)__double2hiint(n1) & 0x7FF00000u, e2 = (uint32_t)__double2hiint(n2) & 0x7FF00000u,
+                   ed = (uint32_t)__double2hiint(den) & 0x7FF00000u;
+    if (ed - 0x39B00000u <= 0x0C800000u && max(e1, e2) <= 0x4FF00000u) { // biased exponent of den in [923, 1123], of n1, n2 <= 1279
+        const double nd = -den;
+        const double r0 = __builtin_amdgcn_rcp(den);
+        const double f0 = fma(nd, r0, 1.0);
+        const double r1 = fma(r0, f0, r0);
+        const double f1 = fma(nd, r1, 1.0);
+        const double r = fma(r1, f1, r1);
+        const double q1 = n1 * r, q2 = n2 * r;
+        Roots out;
+        out.t1 = fma(fma(nd, q1, n1), r, q1);
+        out.t2 = fma(fma(nd, q2, n2), r, q2);
+        return out;
+    }
+    return roots_ordinary(n1, n2, den);
+}
+#else
+RT_HD Roots sphere_roots(double n1, double n2, double den) {
+    Roots r;
+    r.t1 = n1 / den;
+    r.t2 = n2 / den;
+    return r;
+}
+#endif
+
+// Every sphere a segment tests in WORLD space (translation-only sprites: RT_PRIM_SPHERE_T / RT_PRIM_MEDIUM_T, all of book-one)
+// divides by the same 2 d.d, so the refined reciprocal is taken once per segment (trav_begin) and each test's two roots
+// cost mul + fma + fma each.  Valid -- not NaN -- only when the conditions of sphere_roots hold for every such test of the
+// segment: 2 d.d in [2^-100, 2^100], |o| <= 2^100 per component, and (RtLaunch::world_mid, checked at commit) every world-space
+// sphere's centre and radius <= 2^100: then |b| <= 2^155, disc <= 2^311, both numerators <= 2^157 < 2^256.
+#define RTL_NAN (__builtin_nan(""))
+RT_HD double world_roots_rcp(const RtLaunch &L, V3 o, double a) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_PLAIN_DIV3)
+    const double den = 2.0 * a;
+    const uint32_t ed = (uint32_t)__double2hiint(den) & 0x7FF00000u;
+    const uint32_t eo = max(max((uint32_t)__double2hiint(o.x) & 0x7FF00000u, (uint32_t)__double2hiint(o.y) & 0x7FF00000u),
+                            (uint32_t)__double2hiint(o.z) & 0x7FF00000u);
+    if (L.world_mid && ed - 0x39B00000u <= 0x0C800000u && eo <= 0x46300000u) { // den: biased exponent in [923, 1123]; o: <= 1123
+        const double nd = -den;
+        const double r0 = __builtin_amdgcn_rcp(den);
+        const double f0 = fma(nd, r0, 1.0);
+        const double r1 = fma(r0, f0, r0);
+        const double f1 = fma(nd, r1, 1.0);
+        return fma(r1, f1, r1);
+    }
+#endif
+    return RTL_NAN;
+}
+
 // ---- Sphere::hit in the sphere's own frame (src/geometry.rs:43-73) ----
 // oc = local ray origin (centre at 0), a = d.d.  Returns the parametric hit only.
-RT_HD bool sphere_t(V3 oc, V3 d, double a, double radius, double *t_out) {
+// r2a: world_roots_rcp of the segment for a world-space sphere, NaN otherwise
+RT_HD bool sphere_t(V3 oc, V3 d, double a, double radius, double *t_out, double r2a = RTL_NAN) {
     double b = dot(oc, d) * 2.0;
     double c = dot(oc, oc) - radius * radius;
     double disc = b * b - 4.0 * a * c;
     if (disc < 0.0) return false;
     double sq = sqrt(disc);
-    double t1 = (-b - sq) / (2.0 * a);
-    double t2 = (-b + sq) / (2.0 * a);
+    Roots rt;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_PLAIN_DIV3)
+    if (r2a == r2a) {
+        const double n1 = -b - sq, n2 = -b + sq, nd = -(2.0 * a);
+        const double q1 = n1 * r2a, q2 = n2 * r2a;
+        rt.t1 = fma(fma(nd, q1, n1), r2a, q1);
+        rt.t2 = fma(fma(nd, q2, n2), r2a, q2);
+    } else
+#endif
+        rt = sphere_roots(-b - sq, -b + sq, 2.0 * a);
+    const double t1 = rt.t1, t2 = rt.t2;
     // The reference orders the roots here (`if t1 < t2 { (t1, t2) } else { (t2, t1) }`).  That never changes the outcome:
     // sq >= 0 (or -0, NaN) and 2a >= 0 (a sum of squares), so -b - sq <= -b + sq and t1 <= t2 by the monotonicity of
     // rounding; the swap fires only for equal roots or when one is NaN, and then "the first root above 1e-6, else the
@@ -324,6 +399,7 @@ RT_HD bool medium_hit(V3 oc, V3 d, double radius, double neg_inv_density, uint64
 }
 
 struct SegCtx { // what a primitive test may need besides the ray
+    double r2a; // world_roots_rcp of this segment
     uint64_t rng_base;
     uint32_t segment;
     unsigned long long draws;
@@ -473,7 +549,7 @@ RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx
         V3 c = mk(G.g[0], G.g[1], G.g[2]);
         V3 oc = o - c;
         double t;
-        if (!sphere_t(oc, d, a, G.g[3], &t)) return false;
+        if (!sphere_t(oc, d, a, G.g[3], &t, sc.r2a)) return false;
         r->t = t;
         if (RECORD) {
             sphere_finish(oc, d, G.g[3], t, uv, r);
@@ -557,6 +633,7 @@ struct Trav {
     double best_t;
     uint32_t best_prim;
     float best32;        // best_t rounded up to binary32
+    double r2a;          // world_roots_rcp of the segment
     float idx, idy, idz; // 1 / d
     float nx, ny, nz;    // -(o/d + pad): entry planes,  t = plane * id + n
     float fx, fy, fz;    // -(o/d - pad): exit planes
@@ -639,6 +716,8 @@ RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack
     tv.best_t = RTL_INF;
     tv.best_prim = 0xFFFFFFFFu;
     const double a = dot(d, d);
+    tv.r2a = world_roots_rcp(L, o, a);
+    sc.r2a = tv.r2a;
     for (int32_t pi = 0; pi < L.n_hoisted; ++pi) {
         Rec r;
         if (prim_hit<GENERAL, MEDIUM, false>(L, (uint32_t)pi, o, d, a, sc, &r, false)) {
@@ -940,6 +1019,7 @@ RT_HD void start_sample(const RtLaunch &L, uint32_t x, uint32_t y, uint32_t s, P
 template <bool GENERAL, int MEDIUM, bool TEXTURED, class Stack>
 RT_HD void begin_segment(const RtLaunch &L, PathState *ps, Trav &tv, Stack &st, unsigned long long *prims_tested) {
     SegCtx sc;
+    sc.r2a = RTL_NAN; // set by trav_begin
     sc.rng_base = ps->g.base;
     sc.segment = (uint32_t)ps->k;
     sc.draws = 0;
@@ -952,6 +1032,7 @@ RT_HD void begin_segment(const RtLaunch &L, PathState *ps, Trav &tv, Stack &st, 
 template <bool GENERAL, int MEDIUM, bool TEXTURED, class Stack>
 RT_HD void leaf_step(const RtLaunch &L, PathState *ps, Trav &tv, Stack &st, unsigned long long *prims_tested) {
     SegCtx sc;
+    sc.r2a = tv.r2a;
     sc.rng_base = ps->g.base;
     sc.segment = (uint32_t)ps->k;
     sc.draws = 0;
@@ -976,6 +1057,7 @@ RT_HD bool finish_segment(const RtLaunch &L, PathState *ps, const Trav &tv, V3 *
     if (mat == RT_NO_MATERIAL) return true; // src/render.rs:18-20
     const RtMaterial &M = L.materials[mat];
     SegCtx sc;
+    sc.r2a = RTL_NAN; // the record is built at the known t: no roots
     sc.rng_base = ps->g.base;
     sc.segment = (uint32_t)ps->k;
     sc.draws = 0;

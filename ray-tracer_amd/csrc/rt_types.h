@@ -148,6 +148,7 @@ struct RtLaunch {
     int32_t swap_cap;      // entries per class queue of the swap-at-shade queues (rt_kernels.hip)
     uint32_t root;      // reference of the BVH root in the scene's form, or its kDone when every prim is hoisted
     int32_t n_hoisted;  // prims [0, n_hoisted) are tested directly for every segment
+    int32_t world_mid;  // 1: every world-space sphere (RT_PRIM_SPHERE_T / RT_PRIM_MEDIUM_T) has |centre|, |radius| <= 2^100 (rtl::world_roots_rcp)
     int32_t n_prims;
     RtCameraD cam;
     int32_t width, height, spp, max_depth;

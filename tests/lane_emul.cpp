@@ -99,6 +99,7 @@ extern "C" int lane_emul_render(rt_scene *s, const rt_camera *cam, int W, int H,
     L.n_list = s->flat.n_list;
     L.n_nodes = (int)s->flat.nodes.size();
     L.n_hoisted = s->flat.n_hoisted;
+    L.world_mid = s->flat.world_mid ? 1 : 0;
     L.n_prims = s->flat.n_leaf_prims;
     for (int i = 0; i < 3; ++i) {
         L.cam.eye[i] = cam->eye[i];

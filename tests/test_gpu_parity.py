@@ -328,6 +328,27 @@ def test_list_walk_equals_tree_walk_on_the_gpu(rt, scenes, oracle, gpu_device, m
     _close(img, oracle.build_oracle(d).render(200, 200, 16, 100, seed=4, iterative=True, nthreads=8), max_bad=0)
 
 
+@pytest.mark.parametrize("far", [1e20, 3e31, 1e60])
+def test_shared_reciprocal_divisions_keep_their_guards(rt, scenes, oracle, gpu_device, far):
+    """rt_lane.h takes one refined reciprocal for the three quotients of Vec3 / f64, for the two roots of a sphere and, once per
+    segment, for every world-space sphere test -- only for operands in the middle of the exponent range.  Scenes whose
+    coordinates leave it (a mirror ball and a lambertian one far beyond 2^100 = 1.3e30, paths that bounce back from there)
+    must take the ordinary divisions and still match the oracle bit for bit; 1e20 stays inside the range."""
+    d = scenes.SceneDesc()
+    grey, mirror = d.lambertian_rgb((0.6, 0.6, 0.6)), d.mat("metal", d.tex_solid((0.9, 0.9, 0.9)), 0.0)
+    for k in range(6):
+        d.sprite(d.geom("sphere", 0.5), grey if k % 2 else mirror, scenes.mat4_translation((k - 2.5, 0.0, 6.0 + (k % 3))))
+    d.sprite(d.geom("sphere", 0.4 * far), mirror, scenes.mat4_translation((0.9 * far, 0.3 * far, 1.1 * far)))
+    d.sprite(d.geom("sphere", 0.3 * far), grey, scenes.mat4_translation((-0.8 * far, 0.1 * far, 1.2 * far)))
+    d.sprite(d.geom("sphere", 8.0 * far), d.mat("diffuse_light", d.tex_solid((0.8, 0.9, 1.0))), None)
+    d.camera = ((0.0, 0.5, -2.0), (0.0, 0.0, 6.0), (0.0, 1.0, 0.0), 0.9, 4 / 3, 8.0, 0.0)
+    sc, cam = scenes.build_product(d, device=gpu_device)
+    img = sc.render(cam, 96, 72, 16, 30, seed=2)
+    ref = oracle.build_oracle(d).render(96, 72, 16, 30, seed=2, iterative=True, nthreads=8)
+    assert np.isfinite(ref).all() and ref.max() > 0.1
+    _close(img, ref, max_bad=0)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_scenes_match_oracle(rt, scenes, oracle, gpu_device, seed):
     """Random transforms (incl. non-rigid), cubes, media, textures, lens: general kernel vs oracle."""

@@ -1,12 +1,12 @@
 #!/bin/bash
-# GPU box: book-one at full size with the in-tree library and every variant under ray-tracer_amd/lib/variants
+# GPU box: book-one at full size, in-tree library and every variant, 3 rounds interleaved (run-to-run noise is ~0.3 %)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+for round in 1 2 3; do
 for f in $R/ray-tracer_amd/lib/librt_mi355x.so $R/ray-tracer_amd/lib/variants/librt_*.so; do
-  [ -f "$f" ] || continue
-  for e in "X=1" "RT_SWAP=0"; do
-  env $e RT_MI355X_LIB=$f timeout -k 10 300 python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python3 -c "
+ [ -f "$f" ] || continue
+  RT_MI355X_LIB=$f timeout -k 10 300 python3 $R/bench.py --scene book_one --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "
 import sys,json
 d=json.loads([l for l in sys.stdin if l.startswith(chr(123))][-1]); r=d['roofline']
-print('$(basename $f .so) $e', round(d['value'],1), 'Ms/s kernel_ms', round(r['kernel_ms'],1), {k:round(v,2) for k,v in r['simd_utilisation'].items()}, {k:round(v,2) for k,v in r['block_cycle_share'].items()}, 'seg', round(r['segments_per_sample'],2))"
-  done
+print('$(basename $f .so)', round(d['value'],1), 'Ms/s kernel_ms', round(r['kernel_ms'],2))"
+done
 done
