@@ -84,6 +84,10 @@
 #ifndef RT_VOTE_LEAF_G
 #define RT_VOTE_LEAF_G 16
 #endif
+// the lean general family (no media / textures: the Cornell box): shade block 42 % of the time, quorum sweep 32..64 -> 56
+#ifndef RT_VOTE_SHADE_LEAN
+#define RT_VOTE_SHADE_LEAN 56
+#endif
 #ifndef RT_NODE_KEEP_G
 #define RT_NODE_KEEP_G 8
 #endif
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
         }
         const int nS = __popcll(mS), nL = __popcll(mL), nN = __popcll(mN);
 
-        constexpr int kVoteShade = GENERAL ? RT_VOTE_SHADE_G : RT_VOTE_SHADE, kVoteLeaf = GENERAL ? RT_VOTE_LEAF_G : RT_VOTE_LEAF,
+        constexpr int kVoteShade = GENERAL ? (MEDIUM == 0 ? RT_VOTE_SHADE_LEAN : RT_VOTE_SHADE_G) : RT_VOTE_SHADE, kVoteLeaf = GENERAL ? RT_VOTE_LEAF_G : RT_VOTE_LEAF,
                       kNodeKeep = GENERAL ? RT_NODE_KEEP_G : RT_NODE_KEEP;
         if (nS >= kVoteShade || (nN == 0 && nL == 0)) {
             // ---------------- shade block ----------------
