@@ -112,7 +112,9 @@ def issue_roofline(rt, scene, W, H, spp, depth, world, kernel_ms, lane_util):
         return out
     issue = v["issue_cycles_total"]                      # issue cycles per launch (class counts x measured prices)
     achieved = issue / (kernel_ms * 1e-3) / 1e9          # with the kernel duration measured live in this run
-    out.update({"achieved": achieved, "frac": achieved / out["peak"], "useful_frac": achieved / out["peak"] * lane_util,
+    pmc_util = s.get("valu_lane_utilisation")  # SQ_THREAD_CYCLES_VALU / 64 / SQ_ACTIVE_INST_VALU of the profiled launch: every VALU instruction
+    out.update({"achieved": achieved, "frac": achieved / out["peak"], "useful_frac": achieved / out["peak"] * (pmc_util or lane_util),
+                "useful_frac_vote_blocks_only": achieved / out["peak"] * lane_util,
                 "traffic": (s.get("hbm_traffic_bytes_per_launch") or {}).get("total"),
                 "source": f"{prof.relative_to(ROOT)} (rocprofv3 --pmc passes of `{s['command']}`, build {rt.build_hash()}); "
                           f"prices profiles/r02_valu_issue.json; kernel_ms live (HIP events)",
@@ -121,9 +123,9 @@ def issue_roofline(rt, scene, W, H, spp, depth, world, kernel_ms, lane_util):
                 "profiled_kernel_ms": s.get("render_kernel_avg_ms"), "profiled_clock_ghz": v.get("clock_ghz"),
                 "profiled_frac_at_measured_clock": v.get("frac"), "valu_lane_utilisation_pmc": s.get("valu_lane_utilisation"),
                 "lds_conflict_share": s.get("lds_conflict_share_of_lds_active"), "wave_cycle_shares": s.get("wave_cycle_shares"),
-                "note": "frac = VALU issue slots of the whole chip filled during the launch; useful_frac weights it with the lane "
-                        "utilisation of the wave-vote blocks (live counters); >= 0.9 means the kernel can only get faster by "
-                        "executing fewer instructions or wasting fewer lanes"})
+                "note": "frac = VALU issue slots of the whole chip filled during the launch; useful_frac weights it with the VALU lane "
+                        "utilisation of the profiled launch (PMC, every instruction: divergence inside a block included); "
+                        "useful_frac_vote_blocks_only with the occupancy of the wave-vote blocks alone (live counters)"})
     return out
 
 
