@@ -218,6 +218,35 @@ __device__ __forceinline__ void store_sample(double *samples, uint32_t slot, rtl
         o[1] = b;
     }
 }
+// Launch fields that only the refill step needs (camera: 26 dwords, image / shard / job geometry: 17) are NOT read through the
+// by-value kernel argument `L`: the compiler loads every field it sees in the prologue and keeps it in SGPRs for the whole
+// persistent loop -- 66 dwords, of which 40-60 were spilled to VGPR lanes and shuffled back (v_readlane / v_writelane)
+// in every shade block.  They are re-read from the kernel-argument segment (scalar loads) where they are used; the empty
+// asm makes the pointer opaque at that point, so the loads can be neither hoisted out of the loop nor merged with others.
+typedef const __attribute__((address_space(4))) RtLaunch *RtKernArg;
+__device__ __forceinline__ RtKernArg kernarg_now() {
+    RtKernArg p = (RtKernArg)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+struct RtSampleSetup { // what rtl::start_sample reads
+    RtCameraD cam;
+    int32_t width, height, spp;
+    uint64_t seed_mix;
+};
+__device__ __forceinline__ void load_sample_setup(RtKernArg K, RtSampleSetup *su) {
+    for (int i = 0; i < 3; ++i) {
+        su->cam.eye[i] = K->cam.eye[i];
+        su->cam.lower_left[i] = K->cam.lower_left[i];
+        su->cam.horizontal[i] = K->cam.horizontal[i];
+        su->cam.vertical[i] = K->cam.vertical[i];
+    }
+    su->cam.lens_radius = K->cam.lens_radius;
+    su->width = K->width;
+    su->height = K->height;
+    su->spp = K->spp;
+    su->seed_mix = K->seed_mix;
+}
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) { // set bits below this lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -547,7 +576,12 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
             uint32_t new_x = 0, new_y = 0, new_s = 0;
             bool got = false;
             uint32_t job_next = 0, job_left = 0, job_slot0 = 0, job_x0 = 0, job_y0 = 0, job_s_first = 0, job_nspp = 1;
+            uint32_t img_w = 0, img_h = 0, first_s = 0;
             if (do_refill) { // wave-uniform
+                const RtKernArg K = kernarg_now();
+                img_w = (uint32_t)K->width;
+                img_h = (uint32_t)K->height;
+                first_s = (uint32_t)K->s0;
                 const uint4 ja = *reinterpret_cast<const uint4 *>(job_mem), jb = *reinterpret_cast<const uint4 *>(job_mem + 4);
                 job_next = uniform(ja.x);
                 job_left = uniform(ja.y);
@@ -565,21 +599,24 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                     uint32_t j = 0;
                     if (need && lane_rank(m) == 0u) j = atomicAdd(L.job_counter, 1u);
                     j = (uint32_t)__builtin_amdgcn_readlane((int)j, __ffsll((long long)m) - 1); // fetched by the first needing lane
-                    if (j >= (uint32_t)L.n_jobs) {
+                    const RtKernArg K = kernarg_now();
+                    if (j >= (uint32_t)K->n_jobs) {
                         queue_empty = true;
                         break;
                     }
-                    const uint32_t k = j / (uint32_t)L.jobs_per_tile, sub = j - k * (uint32_t)L.jobs_per_tile;
-                    const uint32_t tile = (uint32_t)L.shard_index + k * (uint32_t)L.shard_count;
-                    const uint32_t ty = tile / (uint32_t)L.tiles_x, tx = tile - ty * (uint32_t)L.tiles_x;
+                    const uint32_t jobs_per_tile = (uint32_t)K->jobs_per_tile, tiles_x = (uint32_t)K->tiles_x, s_count = (uint32_t)K->s_count,
+                                   job_spp = (uint32_t)K->job_spp;
+                    const uint32_t k = j / jobs_per_tile, sub = j - k * jobs_per_tile;
+                    const uint32_t tile = (uint32_t)K->shard_index + k * (uint32_t)K->shard_count;
+                    const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
                     job_x0 = tx * RT_TILE_EDGE;
                     job_y0 = ty * RT_TILE_EDGE;
-                    job_s_first = sub * (uint32_t)L.job_spp;
-                    const uint32_t nspp = min((uint32_t)L.job_spp, (uint32_t)L.s_count - job_s_first);
+                    job_s_first = sub * job_spp;
+                    const uint32_t nspp = min(job_spp, s_count - job_s_first);
                     job_left = nspp * RT_TILE_PIXELS;
                     job_nspp = nspp;
                     job_next = 0u;
-                    job_slot0 = (k * (uint32_t)L.s_count + job_s_first) * RT_TILE_PIXELS;
+                    job_slot0 = (k * s_count + job_s_first) * RT_TILE_PIXELS;
                 }
                 const uint32_t take = min((uint32_t)__popcll(m), job_left);
                 const uint32_t rank = lane_rank(m);
@@ -589,11 +626,11 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                     // lanes refilled together start with near-identical rays (+1 % over sample-major)
                     const uint32_t pix = n / job_nspp, sj = n - pix * job_nspp;
                     const uint32_t x = job_x0 + (pix & 7u), y = job_y0 + (pix >> 3);
-                    if (x < (uint32_t)L.width && y < (uint32_t)L.height) {
+                    if (x < img_w && y < img_h) {
                         slot = job_slot0 + sj * RT_TILE_PIXELS + pix;
                         new_x = x;
                         new_y = y;
-                        new_s = (uint32_t)L.s0 + job_s_first + sj;
+                        new_s = first_s + job_s_first + sj;
                         got = true;
                         need = false;
                     }
@@ -606,9 +643,13 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                 *reinterpret_cast<uint4 *>(job_mem) = make_uint4(job_next, job_left, job_slot0, job_x0);
                 *reinterpret_cast<uint4 *>(job_mem + 4) = make_uint4(job_y0, job_s_first, job_nspp, 0u);
             }
-            if (got) {
-                rtl::start_sample<LENS>(L, new_x, new_y, new_s, &ps);
-                has_path = true;
+            if (__ballot(got) != 0ull) { // wave-uniform: the setup is read with scalar loads
+                RtSampleSetup su;
+                load_sample_setup(kernarg_now(), &su);
+                if (got) {
+                    rtl::start_sample<LENS>(su, new_x, new_y, new_s, &ps);
+                    has_path = true;
+                }
             }
             RT_STAMP(t0);
             t_ref += t0 - t1;

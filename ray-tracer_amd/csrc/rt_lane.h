@@ -1002,8 +1002,9 @@ struct PathState {
 };
 
 // examples/book-one.rs:69-73: stream, jitter, camera ray
-template <bool LENS>
-RT_HD void start_sample(const RtLaunch &L, uint32_t x, uint32_t y, uint32_t s, PathState *ps) {
+// LaunchT: RtLaunch, or the kernel's RtSampleSetup (the same fields, re-read from the kernel-argument segment per refill)
+template <bool LENS, class LaunchT>
+RT_HD void start_sample(const LaunchT &L, uint32_t x, uint32_t y, uint32_t s, PathState *ps) {
     const uint64_t pixel = (uint64_t)y * (uint64_t)L.width + (uint64_t)x;
     const uint64_t stream = pixel * (uint64_t)L.spp + (uint64_t)s;
     ps->g.base = L.seed_mix + (stream << RT_RNG_STREAM_SHIFT) * RT_RNG_GAMMA;
