@@ -12,7 +12,7 @@ for f in rt_host rt_api; do
   g++ -O1 -g -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fsanitize=address,undefined -fno-omit-frame-pointer \
       -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -DRT_SOURCE_HASH="\"$H\"" -c $f.cpp -o $O/$f.o
 done
-g++ -shared -fPIC -fsanitize=address,undefined -o $O/librt_asan.so $O/rt_host.o $O/rt_api.o _obj/rt_kernels.o -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
+g++ -shared -fPIC -fsanitize=address,undefined -o $O/librt_asan.so $O/rt_host.o $O/rt_api.o _obj/rt_kernels.o _obj/rt_kernels_media.o -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
 cd $R
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
   RT_MI355X_LIB=$O/librt_asan.so python -m pytest tests -m "not gpu" -x -q
