@@ -632,3 +632,36 @@ def test_bench_two_ranks_rehearsal(gpu_device):
     assert [a["rank"] for a in d["step_anatomy_ms"]] == [0, 1]
     assert all(a["render_ms"] > 0 and "gather_ms" in a for a in d["step_anatomy_ms"])
     assert d["roofline"]["frac"] is None and "N = 1" in d["roofline"]["reason"]
+
+
+def test_bench_line_contract(gpu_device):
+    """The default `python bench.py` line (N = 1, BASELINE.json configs[1]): metric / unit / dtype / config as the driver expects
+    them, a roofline object whose fraction is a fraction (from the committed rocprofv3 counts when they belong to this build,
+    else null with a reason -- never a stale number), HBM traffic below the records' size x 1.5, and a CPU baseline of kind
+    "port" on a bounded sample."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-seconds", "3"],
+                       capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.split("\n") if ln.startswith("{")]
+    assert len(lines) == 1  # ONE JSON line
+    d = json.loads(lines[0])
+    assert d["unit"] == "Msamples/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "book-one" in d["metric"] and "1200x800" in d["config"]["workload"] and "configs[1]" in d["config"]["workload"]
+    assert d["value"] > 1000.0  # the north star's bar on one MI355X
+    assert abs(d["value"] - 2 * 1200 * 800 * 500 / d["wall_s"] / 1e6) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "valu_issue" and rf["kernel"] == "render_kernel" and rf["kernel_ms"] > 0
+    if rf["frac"] is None:
+        assert rf["reason"]  # profile of another build / workload: said so, no number
+    else:
+        assert 0.3 < rf["frac"] <= 1.0 and 0.1 < rf["useful_frac"] <= rf["frac"]
+        assert rf["source"].startswith("profiles/r02_book_one/summary.json")
+        assert 15.36e9 <= rf["traffic"] < 1.5 * 15.36e9  # one 32-byte record per sample, written once
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "Msamples/s" and cb["cores"] >= 1 and 0 < cb["value"] < d["value"] / 10
