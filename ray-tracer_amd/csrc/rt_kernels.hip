@@ -54,7 +54,7 @@
 #define RT_BLOCK 512 /* threads per workgroup: 8 waves share one LDS copy of the node array */
 #endif
 #ifndef RT_BLOCK_GENERAL
-#define RT_BLOCK_GENERAL 512 /* kernel with media over general boundaries: 256 VGPRs, 2 waves per SIMD = one workgroup per CU */
+#define RT_BLOCK_GENERAL 256 /* kernel with media over general boundaries: 3 waves per SIMD as three groups per CU */
 #endif
 #ifndef RT_BLOCK_MEDIUM
 #define RT_BLOCK_MEDIUM 256 /* general prims + sphere media + textures (the book-two cover): 3 waves per SIMD as three groups per CU */
@@ -98,7 +98,8 @@
 #define RT_WAVES_PER_EU_LEAN 4 /* general prims without media / textures: 128 VGPRs, four 256-thread groups per CU (+15 % on the Cornell box over 3) */
 #endif
 #ifndef RT_WAVES_PER_EU_GENERAL
-#define RT_WAVES_PER_EU_GENERAL 2 /* media over general boundaries (medium_general_hit) need the registers */
+#define RT_WAVES_PER_EU_GENERAL 3 /* media over general boundaries: 168 VGPRs + 144 B of scratch per lane beat 214 VGPRs at 2 waves per
+                                     SIMD without scratch (instanced scene 46.7 vs 55.8 ms); 4 waves (128 VGPRs, 320 B) lose: 65.3 */
 #endif
 #ifndef RT_WAVES_PER_EU_MEDIUM
 #define RT_WAVES_PER_EU_MEDIUM 4
