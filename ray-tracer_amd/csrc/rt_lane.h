@@ -785,6 +785,9 @@ RT_HD void trav_list_step(const float *boxes, uint32_t n, uint32_t first_prim, T
                 *bz = reinterpret_cast<const float *>(base + tv.oz);
     float near_t = 0.0f;
     uint32_t near_ref = Ref::kDone;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 6
+#endif
     for (uint32_t b = 0; b < n; ++b) {
         const float tmin = fmaxf(fmaxf(fmaf(bx[0], tv.idx, tv.nx), fmaf(by[0], tv.idy, tv.ny)), fmaxf(fmaf(bz[0], tv.idz, tv.nz), 0.0f));
         const float tmax = fminf(fminf(fmaf(bx[1], tv.idx, tv.fx), fmaf(by[1], tv.idy, tv.fy)), fminf(fmaf(bz[1], tv.idz, tv.fz), tv.best32));
