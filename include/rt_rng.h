@@ -73,7 +73,23 @@ RT_HD uint64_t rt_rng_base(uint64_t seed, uint64_t stream) {
     return rt_mix64(seed) + (stream << RT_RNG_STREAM_SHIFT) * RT_RNG_GAMMA;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+/* two funnel shifts (v_alignbit_b32: the low word of {a, b} >> s) instead of 64-bit shifts and an or */
+RT_HD uint64_t rt_rotl64(uint64_t x, int k) {
+    uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
+    if (k >= 32) { /* constant at every call site */
+        const uint32_t t = hi;
+        hi = lo;
+        lo = t;
+        k -= 32;
+    }
+    if (k == 0) return ((uint64_t)hi << 32) | lo;
+    const uint32_t nh = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(32 - k)), nl = __builtin_amdgcn_alignbit(lo, hi, (uint32_t)(32 - k));
+    return ((uint64_t)nh << 32) | nl;
+}
+#else
 RT_HD uint64_t rt_rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+#endif
 
 /* seed the xoroshiro128+ state from the stream key */
 RT_HD void rt_rng_seed_state(uint64_t base, uint64_t *s0, uint64_t *s1) {
@@ -129,6 +145,22 @@ RT_HD double rt_bits_to_double(uint64_t b) {
 /* rand 0.7 Standard for f64: 53 random bits, [0,1) */
 RT_HD double rt_u64_to_unit53(uint64_t x) {
     return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+
+/* `random::<f64>() * 2.0 - 1.0`, a coordinate of randomInUnitSphere's candidate point (src/util.rs:8-12), exactly: with
+ * k = x >> 11 < 2^53 the reference's value is fl(fl(fl(k * 2^-53) * 2) - 1) = k * 2^-52 - 1 with NO rounding anywhere (a 53-bit
+ * integer scaled by a power of two; doubling; and k * 2^-52 - 1 is a multiple of 2^-52 below 1 in magnitude).  The device
+ * builds the same number from bits: 1.m = 1 + (k mod 2^52) * 2^-52, minus 1 when bit 52 of k is set, minus 2 when it is not --
+ * both differences are exact (Sterbenz) -- instead of a 64-bit integer conversion, two multiplications and a subtraction. */
+RT_HD double rt_u64_to_pm1(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
+    const uint32_t mhi = 0x3FF00000u | ((hi >> 11) & 0xFFFFFu), mlo = (hi << 21) | (lo >> 11);
+    const double one_m = __hiloint2double((int)mhi, (int)mlo);
+    return one_m - (((int32_t)hi < 0) ? 1.0 : 2.0);
+#else
+    return rt_u64_to_unit53(x) * 2.0 - 1.0;
+#endif
 }
 
 /* 1.mantissa in [1,2), 52 random bits (rand 0.7 into_float_with_exponent(0)) */

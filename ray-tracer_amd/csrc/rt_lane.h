@@ -106,6 +106,10 @@ RT_HD double rng_unit53(Rng &g) { // rand::random::<f64>()
     ++g.draws;
     return rt_u64_to_unit53(rt_xoroshiro_next(&g.s0, &g.s1));
 }
+RT_HD double rng_pm1(Rng &g) { // rand::random::<f64>() * 2.0 - 1.0 (exact, see rt_u64_to_pm1)
+    ++g.draws;
+    return rt_u64_to_pm1(rt_xoroshiro_next(&g.s0, &g.s1));
+}
 RT_HD double rng_range01(Rng &g) { // gen_range(0.0, 1.0)
     ++g.draws;
     return rt_u64_to_range01(rt_xoroshiro_next(&g.s0, &g.s1));
@@ -129,20 +133,16 @@ RT_HD V3 random_in_unit_sphere_bounded(Rng &g, int max_iter, bool *ok) {
             break;
         }
         ++it;
-        double a = rng_unit53(g);
-        double b = rng_unit53(g);
-        double c = rng_unit53(g);
-        p = mk(a * 2.0 - 1.0, b * 2.0 - 1.0, c * 2.0 - 1.0);
+        const double a = rng_pm1(g), b = rng_pm1(g), c = rng_pm1(g); // random::<f64>() * 2.0 - 1.0, three draws in order
+        p = mk(a, b, c);
     }
     return p;
 }
 RT_HD V3 random_in_unit_sphere(Rng &g) { // src/util.rs:6-15
     V3 p = mk(1.0, 1.0, 1.0);
     while (dot(p, p) >= 1.0) {
-        double a = rng_unit53(g);
-        double b = rng_unit53(g);
-        double c = rng_unit53(g);
-        p = mk(a * 2.0 - 1.0, b * 2.0 - 1.0, c * 2.0 - 1.0);
+        const double a = rng_pm1(g), b = rng_pm1(g), c = rng_pm1(g); // random::<f64>() * 2.0 - 1.0, three draws in order
+        p = mk(a, b, c);
     }
     return p;
 }
