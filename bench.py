@@ -129,20 +129,45 @@ def issue_roofline(rt, scene, W, H, spp, depth, world, kernel_ms, lane_util):
     return out
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD process (this process has
+    not touched the GPU and never execs), relay the one JSON line of rank 0 and the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:  # a free port for the rendezvous
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)  # stderr passes through
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in r.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    if r.returncode == 0 and not lines:
+        print("[bench] the ranks exited 0 but rank 0 printed no result line", file=sys.stderr)
+        return 1
+    return r.returncode
+
+
 def main():
     a = parse()
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    from __graft_entry__ import load_package
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+            raise SystemExit(spawn_ranks(a.gpus))
         raise SystemExit(f"--gpus {a.gpus} does not match WORLD_SIZE {world}")
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
     if a.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)

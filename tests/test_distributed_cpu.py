@@ -55,3 +55,19 @@ def test_tile_sharding_gather_unpack(world, W, H, rt, lane_emul):
         p.join(timeout=180)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_bench_gpus_n_without_a_launcher_relays_failure():
+    """`python bench.py --gpus 2` with no WORLD_SIZE starts its own ranks (a child torch.distributed.run).  Without a GPU
+    every rank fails: the launcher's non-zero exit code comes back and NO result line is printed -- never a silent
+    single-rank run.  (The successful form of the same command is a -m gpu test.)"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: covered by tests/test_gpu_parity.py::test_bench_gpus_n_starts_its_own_ranks")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "1",
+                        "--warmup", "0", "--width", "64", "--height", "64", "--spp", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=str(ROOT))
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.split("\n") if ln.startswith("{")], r.stdout
+    assert "nproc-per-node" not in r.stdout  # the old usage message is gone

@@ -634,6 +634,26 @@ def test_bench_two_ranks_rehearsal(gpu_device):
     assert d["roofline"]["frac"] is None and "N = 1" in d["roofline"]["reason"]
 
 
+def test_bench_gpus_n_starts_its_own_ranks(gpu_device):
+    """`python3 bench.py --gpus 2 ...` with NO launcher and no WORLD_SIZE in the environment: bench.py starts
+    torch.distributed.run itself as a child process, relays rank 0's one JSON line and the exit code."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "1",
+                        "--warmup", "0", "--width", "240", "--height", "160", "--spp", "8", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.split("\n") if ln.strip()]
+    assert len(lines) == 1, lines  # ONE line on stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["image_matches_single_gpu"] is True
+
+
 def test_bench_line_contract(gpu_device):
     """The default `python bench.py` line (N = 1, BASELINE.json configs[1]): metric / unit / dtype / config as the driver expects
     them, a roofline object whose fraction is a fraction (from the committed rocprofv3 counts when they belong to this build,
