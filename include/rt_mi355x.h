@@ -98,8 +98,8 @@ int rt_add_geometry_transformed(rt_scene *, int geometry, const double transform
  * The listed sprites are moved into the node (like the Vec the constructor takes): they stop being part of the world's
  * own list and are hit only through sprites whose geometry is this node.  A child without a material is the reference's
  * TransformedGeometry.  Whatever material a child carries, Sprite::hit of the enclosing sprite replaces it
- * (src/sprite.rs:119-127).  RT_ERR_EMPTY for an empty list (None upstream).  Nesting: up to 4 transform levels above
- * a sphere / rectangle.  At commit every instance is expanded into leaves that keep the matrices of all their levels --
+ * (src/sprite.rs:119-127).  RT_ERR_EMPTY for an empty list (None upstream).  Nesting: up to 15 transform levels above
+ * a sphere / rectangle (more than 4: RT_FEAT_DEEP_CHAIN, served by the slower kernel family for general media).  At commit every instance is expanded into leaves that keep the matrices of all their levels --
  * the traversal stays one flat BVH and the arithmetic per level is the reference's. */
 int rt_add_geometry_bvh(rt_scene *, const int *sprites, int n_sprites);
 
@@ -206,6 +206,28 @@ int rt_render_tiles_device(rt_scene *, const rt_camera *, const rt_render_params
  * back to back (what one RCCL gather of equal-sized chunks produces). */
 int rt_unpack_tiles_device(const void *d_gathered, int tiles_per_shard_padded, int shard_count, int width, int height,
                            void *d_image_out, void *stream);
+/* The same two permutations on HOST memory, for callers whose gather ends in host buffers (a gloo / MPI gather, a
+ * checkpoint): rt_pack_tiles_host copies this shard's pixels of a row-major image [y][x][3] into the packed layout of
+ * rt_render_tiles_device (`tiles_padded` >= rt_shard_tile_count tiles, the rest and pixels outside the image zero);
+ * rt_unpack_tiles_host is rt_unpack_tiles_device on host pointers.  Pure index work, no arithmetic. */
+int rt_pack_tiles_host(const double *image, int width, int height, int shard_index, int shard_count, int tiles_padded, double *tiles_out);
+int rt_unpack_tiles_host(const double *gathered, int tiles_per_shard_padded, int shard_count, int width, int height, double *image_out);
+/* Status of the renders launched on this scene so far: waits for them, then returns RT_OK or RT_ERR_DEVICE when a kernel
+ * set the device error word (launched with fewer LDS bytes than its layout needs; the counting build's progress watchdog:
+ * ray-tracer_amd/csrc/rt_lds.h) -- a persistent kernel cannot fail any other way than by hanging, so it reports instead.
+ * rt_render / rt_render_progressive / rt_last_kernel_ms check it themselves; callers of the asynchronous
+ * rt_render_tiles_device call this once their stream has drained (or whenever they want to wait). */
+int rt_render_status(rt_scene *);
+/* Per-sample workspace.  A render keeps one 32-byte record per sample of a pass in device memory (width x height x spp x 32 B
+ * / shard_count for one pass: 15.36 GB for 1200x800x500), written once by render_kernel and summed in sample order by
+ * reduce_kernel; a scene holds one such buffer per render slot in use (one unless two renders overlap), sized to the largest
+ * render so far, reused by later ones.  The limit per slot is the smaller of 32 GiB and a quarter of the device's memory
+ * unless set here (bytes; 0 restores the default) or through RT_SAMPLE_WORKSPACE_MB; renders that need more run in several
+ * passes (bit-identical).  rt_scene_trim waits for the scene's renders and gives the buffers back;
+ * rt_scene_workspace_bytes reports what the scene holds now. */
+int rt_scene_set_workspace_limit(rt_scene *, size_t bytes);
+int rt_scene_trim(rt_scene *);
+size_t rt_scene_workspace_bytes(const rt_scene *);
 /* time (ms) the last rt_render / rt_render_tiles_device kernel took on its stream,
  * measured with HIP events recorded around the launch; blocks until it finished */
 int rt_last_kernel_ms(rt_scene *, float *ms);
@@ -272,6 +294,7 @@ int rt_probe_device_math(int device, const double *a, const double *b, int n, do
 #define RT_FEAT_LENS 16u
 #define RT_FEAT_WIDE 64u           /* more than 32767 prims or nodes: 32-bit node references, two LDS words per stack entry */
 #define RT_FEAT_MEDIUM_GENERAL 32u /* a ConstantMedium whose boundary is not a plain sphere under a pure translation */
+#define RT_FEAT_DEEP_CHAIN 128u    /* more than four transform levels above a primitive (up to 15): served by the same kernel family */
 
 #ifdef __cplusplus
 }

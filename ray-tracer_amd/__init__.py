@@ -27,6 +27,8 @@ LIB_PATH = Path(os.environ.get("RT_MI355X_LIB") or (_HERE / "lib" / "librt_mi355
 RT_TILE = 8
 RT_FLAG_COUNTERS = 1
 RT_FEAT_SPHERE_T, RT_FEAT_GENERAL, RT_FEAT_MEDIUM, RT_FEAT_TEXTURED, RT_FEAT_LENS, RT_FEAT_MEDIUM_GENERAL, RT_FEAT_WIDE = 1, 2, 4, 8, 16, 32, 64
+RT_FEAT_DEEP_CHAIN = FEAT_DEEP_CHAIN = 128
+ERR_INVALID, ERR_EMPTY, ERR_DEVICE, ERR_UNSUPPORTED, ERR_STATE = -1, -2, -3, -4, -5  # include/rt_mi355x.h RT_ERR_*
 
 
 class RtError(RuntimeError):
@@ -118,6 +120,12 @@ ABI = {
     "rt_shard_tile_count": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "rt_render_tiles_device": (C.c_int, [_VP, C.POINTER(rt_camera), C.POINTER(rt_render_params), _VP, _VP, _VP]),
     "rt_unpack_tiles_device": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, _VP]),
+    "rt_pack_tiles_host": (C.c_int, [_DP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _DP]),
+    "rt_unpack_tiles_host": (C.c_int, [_DP, C.c_int, C.c_int, C.c_int, C.c_int, _DP]),
+    "rt_render_status": (C.c_int, [_VP]),
+    "rt_scene_set_workspace_limit": (C.c_int, [_VP, C.c_size_t]),
+    "rt_scene_trim": (C.c_int, [_VP]),
+    "rt_scene_workspace_bytes": (C.c_size_t, [_VP]),
     "rt_last_kernel_ms": (C.c_int, [_VP, C.POINTER(C.c_float)]),
     "rt_last_launch_config": (C.c_int, [_VP, C.POINTER(rt_launch_config)]),
     "rt_tonemap_rgb8": (None, [_DP, C.c_size_t, C.POINTER(C.c_uint8)]),
@@ -210,16 +218,30 @@ class Mat4:
 class Scene:
     """Records textures / materials / geometries / sprites through the C ABI."""
 
-    def __init__(self, handle=None):
+    def __init__(self, handle=None, committed=False):
         self._h = handle if handle is not None else lib().rt_scene_create()
-        self.committed = handle is not None
+        self.committed = committed
 
     def clone(self, device: int) -> "Scene":
-        """a second committed copy of this scene on another device (rt_scene_clone)"""
+        """a copy of this scene's description, committed on `device` when this one is committed (rt_scene_clone)"""
         h = lib().rt_scene_clone(self._h, device)
         if not h:
             raise RtError(-3, lib().rt_last_error().decode())
-        return Scene(h)
+        return Scene(h, committed=self.committed)
+
+    def status(self):
+        """wait for the renders launched on this scene and raise RtError if a kernel reported a device error (rt_render_status)"""
+        _check(lib().rt_render_status(self._h))
+
+    def set_workspace_limit(self, n_bytes: int):
+        _check(lib().rt_scene_set_workspace_limit(self._h, int(n_bytes)))
+
+    def trim(self):
+        """give the per-sample workspace back (rt_scene_trim)"""
+        _check(lib().rt_scene_trim(self._h))
+
+    def workspace_bytes(self) -> int:
+        return int(lib().rt_scene_workspace_bytes(self._h))
 
     def close(self):
         if self._h:
@@ -370,6 +392,24 @@ def shard_tile_count(width, height, shard_index, shard_count) -> int:
     return _check(lib().rt_shard_tile_count(width, height, shard_index, shard_count))
 
 
+def pack_tiles_host(image: np.ndarray, shard_index: int, shard_count: int, tiles_padded: int) -> np.ndarray:
+    """this shard's pixels of a row-major image in the packed layout of render_tiles_device (rt_pack_tiles_host)"""
+    a = np.ascontiguousarray(image, dtype=np.float64)
+    h, w, _ = a.shape
+    out = np.empty((tiles_padded, 64, 3))
+    _check(lib().rt_pack_tiles_host(_dp(a), w, h, shard_index, shard_count, tiles_padded, _dp(out)))
+    return out
+
+
+def unpack_tiles_host(gathered: np.ndarray, tiles_per_shard_padded: int, shard_count: int, width: int, height: int) -> np.ndarray:
+    """gathered shards [shard][tile][64][3] -> row-major image (rt_unpack_tiles_host)"""
+    g = np.ascontiguousarray(gathered, dtype=np.float64)
+    assert g.size == shard_count * tiles_per_shard_padded * 64 * 3
+    out = np.zeros((height, width, 3))
+    _check(lib().rt_unpack_tiles_host(_dp(g), tiles_per_shard_padded, shard_count, width, height, _dp(out)))
+    return out
+
+
 def unpack_tiles_device(d_gathered_ptr, tiles_per_shard_padded, shard_count, width, height, d_image_ptr, stream_ptr=None):
     _check(lib().rt_unpack_tiles_device(d_gathered_ptr, tiles_per_shard_padded, shard_count, width, height, d_image_ptr,
                                         stream_ptr))
@@ -402,7 +442,7 @@ def tonemap_png8(img: np.ndarray) -> np.ndarray:
     return out
 
 
-HASHED_SOURCES = ("csrc/rt_kernels.hip", "csrc/rt_lane.h", "csrc/rt_types.h", "csrc/rt_host.cpp", "csrc/rt_host.h", "csrc/rt_api.cpp",
+HASHED_SOURCES = ("csrc/rt_kernels.hip", "csrc/rt_lane.h", "csrc/rt_types.h", "csrc/rt_lds.h", "csrc/rt_host.cpp", "csrc/rt_host.h", "csrc/rt_api.cpp",
                   "csrc/rt_scene_priv.h", "../include/rt_mi355x.h", "../include/rt_rng.h", "csrc/Makefile")
 
 

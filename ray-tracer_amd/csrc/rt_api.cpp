@@ -6,6 +6,7 @@
 #include "../../include/rt_mi355x.h"
 #include "../../include/rt_rng.h"
 #include "rt_host.h"
+#include "rt_lds.h"
 #include "rt_scene_priv.h"
 #include "rt_types.h"
 
@@ -27,10 +28,6 @@ extern "C" int rt_launch_reduce(const double *samples, double *tiles, int n_owne
                                 int spp, int width, int height, int shard_index, int shard_count, void *stream);
 extern "C" int rt_kernel_block_size(unsigned features);
 extern "C" int rt_kernel_waves_per_simd(unsigned features);
-extern "C" unsigned rt_swap_lds_bytes(unsigned cap);
-extern "C" unsigned rt_swap_cap_max(void);
-extern "C" unsigned rt_stack_entry_bytes(int wide);
-extern "C" unsigned rt_job_lds_bytes(unsigned features);
 extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int ldsnodes, unsigned lds_bytes, int *blocks_per_cu,
                                     int *n_cu);
 extern "C" int rt_launch_unpack(const double *gathered, int tiles_per_shard, int shard_count, int width, int height,
@@ -63,6 +60,21 @@ int upload(const std::vector<T> &v, void **dptr, size_t *total) {
     HIP_TRY(hipMemcpy(*dptr, v.data(), bytes, hipMemcpyHostToDevice));
     *total += bytes;
     return RT_OK;
+}
+
+// f(index into the packed tiles, index into the row-major image) for every pixel of the shard inside the image
+template <class F>
+void for_each_shard_pixel(int width, int height, int shard_index, int shard_count, int n_owned, F &&f) {
+    const int tx_n = (width + RT_TILE - 1) / RT_TILE;
+    for (int k = 0; k < n_owned; ++k) {
+        const int tile = shard_index + k * shard_count;
+        const int tx = tile % tx_n, ty = tile / tx_n;
+        for (int lane = 0; lane < RT_TILE_PIXELS; ++lane) {
+            const int x = tx * RT_TILE + (lane & 7), y = ty * RT_TILE + (lane >> 3);
+            if (x >= width || y >= height) continue;
+            f(((size_t)k * RT_TILE_PIXELS + (size_t)lane) * 3, ((size_t)y * (size_t)width + (size_t)x) * 3);
+        }
+    }
 }
 
 } // namespace
@@ -98,14 +110,18 @@ void rt_scene_destroy(rt_scene *s) {
 }
 
 static int check_open(rt_scene *s) {
-    if (!s) return fail(RT_ERR_INVALID, "null scene");
     if (s->committed) return fail(RT_ERR_STATE, "scene is immutable after rt_scene_commit");
     return RT_OK;
 }
+// every recording call holds the scene's mutex (rt_scene_clone copies the description under it)
+#define RT_RECORDING(s)                                      \
+    if (!(s)) return fail(RT_ERR_INVALID, "null scene");     \
+    std::lock_guard<std::mutex> recording_lock_((s)->mu);    \
+    if (int e_ = check_open(s)) return e_
 static bool tex_ok(const rt_scene *s, int t) { return t >= 0 && (size_t)t < s->ir.textures.size(); }
 
 int rt_add_texture_solid(rt_scene *s, const double rgb[3]) {
-    if (int e = check_open(s)) return e;
+    RT_RECORDING(s);
     if (!rgb) return fail(RT_ERR_INVALID, "rgb is null");
     rt::TextureIR t{};
     t.kind = RT_TEX_SOLID;
@@ -114,7 +130,7 @@ int rt_add_texture_solid(rt_scene *s, const double rgb[3]) {
     return (int)s->ir.textures.size() - 1;
 }
 int rt_add_texture_checker(rt_scene *s, int black, int white) {
-    if (int e = check_open(s)) return e;
+    RT_RECORDING(s);
     if (!tex_ok(s, black) || !tex_ok(s, white)) return fail(RT_ERR_INVALID, "checker: unknown texture id");
     rt::TextureIR t{};
     t.kind = RT_TEX_CHECKER;
@@ -124,7 +140,7 @@ int rt_add_texture_checker(rt_scene *s, int black, int white) {
     return (int)s->ir.textures.size() - 1;
 }
 int rt_add_texture_image_rgb8(rt_scene *s, const uint8_t *rgb, int w, int h) {
-    if (int e = check_open(s)) return e;
+    RT_RECORDING(s);
     if (!rgb || w <= 0 || h <= 0) return fail(RT_ERR_INVALID, "image texture: null data or empty size");
     rt::TextureIR t{};
     t.kind = RT_TEX_IMAGE;
@@ -136,7 +152,7 @@ int rt_add_texture_image_rgb8(rt_scene *s, const uint8_t *rgb, int w, int h) {
 }
 
 static int add_material(rt_scene *s, uint32_t kind, int tex, double param, bool needs_tex) {
-    if (int e = check_open(s)) return e;
+    RT_RECORDING(s);
     if (needs_tex && !tex_ok(s, tex)) return fail(RT_ERR_INVALID, "material: unknown texture id");
     s->ir.materials.push_back(rt::MaterialIR{kind, tex, param});
     return (int)s->ir.materials.size() - 1;
@@ -147,8 +163,7 @@ int rt_add_material_dielectric(rt_scene *s, double refractive) { return add_mate
 int rt_add_material_diffuse_light(rt_scene *s, int tex) { return add_material(s, RT_MAT_DIFFUSE_LIGHT, tex, 0.0, true); }
 int rt_add_material_isotropic(rt_scene *s, int tex) { return add_material(s, RT_MAT_ISOTROPIC, tex, 0.0, true); }
 
-static int add_geometry(rt_scene *s, rt::GeometryKind k, double a, double b, double c, int boundary) {
-    if (int e = check_open(s)) return e;
+static int add_geometry_locked(rt_scene *s, rt::GeometryKind k, double a, double b, double c, int boundary) { // caller holds s->mu
     rt::GeometryIR g{};
     g.kind = k;
     g.p[0] = a;
@@ -158,20 +173,24 @@ static int add_geometry(rt_scene *s, rt::GeometryKind k, double a, double b, dou
     s->ir.geometries.push_back(g);
     return (int)s->ir.geometries.size() - 1;
 }
-int rt_add_geometry_sphere(rt_scene *s, double r) { return add_geometry(s, rt::GEO_SPHERE, r, 0, 0, -1); }
-int rt_add_geometry_rectangle(rt_scene *s, double w, double h) { return add_geometry(s, rt::GEO_RECTANGLE, w, h, 0, -1); }
-int rt_add_geometry_cube(rt_scene *s, double w, double h, double d) { return add_geometry(s, rt::GEO_CUBE, w, h, d, -1); }
+static int add_geometry(rt_scene *s, rt::GeometryKind k, double a, double b, double c) {
+    RT_RECORDING(s);
+    return add_geometry_locked(s, k, a, b, c, -1);
+}
+int rt_add_geometry_sphere(rt_scene *s, double r) { return add_geometry(s, rt::GEO_SPHERE, r, 0, 0); }
+int rt_add_geometry_rectangle(rt_scene *s, double w, double h) { return add_geometry(s, rt::GEO_RECTANGLE, w, h, 0); }
+int rt_add_geometry_cube(rt_scene *s, double w, double h, double d) { return add_geometry(s, rt::GEO_CUBE, w, h, d); }
 int rt_add_geometry_constant_medium(rt_scene *s, int boundary, double density) {
-    if (int e = check_open(s)) return e;
+    RT_RECORDING(s);
     if (boundary < 0 || (size_t)boundary >= s->ir.geometries.size()) return fail(RT_ERR_INVALID, "medium: unknown boundary geometry");
     if (s->ir.geometries[(size_t)boundary].kind == rt::GEO_MEDIUM)
         return fail(RT_ERR_UNSUPPORTED, "medium: the boundary of a ConstantMedium cannot itself be a ConstantMedium");
-    return add_geometry(s, rt::GEO_MEDIUM, density, 0, 0, boundary);
+    return add_geometry_locked(s, rt::GEO_MEDIUM, density, 0, 0, boundary);
 }
 int rt_add_geometry_transformed(rt_scene *s, int geometry, const double M[16]) {
-    if (int e = check_open(s)) return e;
+    RT_RECORDING(s);
     if (geometry < 0 || (size_t)geometry >= s->ir.geometries.size()) return fail(RT_ERR_INVALID, "transformed: unknown geometry id");
-    const int id = add_geometry(s, rt::GEO_TRANSFORMED, 0, 0, 0, geometry);
+    const int id = add_geometry_locked(s, rt::GEO_TRANSFORMED, 0, 0, 0, geometry);
     if (id < 0) return id;
     if (M)
         std::memcpy(s->ir.geometries[(size_t)id].M, M, sizeof(double) * 16);
@@ -180,7 +199,7 @@ int rt_add_geometry_transformed(rt_scene *s, int geometry, const double M[16]) {
     return id;
 }
 int rt_add_geometry_bvh(rt_scene *s, const int *sprites, int n) {
-    if (int e = check_open(s)) return e;
+    RT_RECORDING(s);
     if (n < 0 || (n > 0 && !sprites)) return fail(RT_ERR_INVALID, "bvh: bad sprite list");
     if (n == 0) return fail(RT_ERR_EMPTY, "BoundingVolumeHierarchyNode::new(vec![]) is None (src/optimize.rs:367-370)");
     for (int i = 0; i < n; ++i) {
@@ -189,7 +208,7 @@ int rt_add_geometry_bvh(rt_scene *s, const int *sprites, int n) {
         for (int j = 0; j < i; ++j)
             if (sprites[j] == sprites[i]) return fail(RT_ERR_INVALID, "bvh: sprite listed twice");
     }
-    const int id = add_geometry(s, rt::GEO_BVH, 0, 0, 0, -1);
+    const int id = add_geometry_locked(s, rt::GEO_BVH, 0, 0, 0, -1);
     if (id < 0) return id;
     s->ir.geometries[(size_t)id].children.assign(sprites, sprites + n);
     for (int i = 0; i < n; ++i) s->ir.sprites[(size_t)sprites[i]].owned = true;
@@ -197,7 +216,7 @@ int rt_add_geometry_bvh(rt_scene *s, const int *sprites, int n) {
 }
 
 int rt_add_sprite(rt_scene *s, int geometry, int material, const double M[16]) {
-    if (int e = check_open(s)) return e;
+    RT_RECORDING(s);
     if (geometry >= (int)s->ir.geometries.size()) return fail(RT_ERR_INVALID, "sprite: unknown geometry id");
     if (material >= (int)s->ir.materials.size()) return fail(RT_ERR_INVALID, "sprite: unknown material id");
     rt::SpriteIR sp{};
@@ -213,6 +232,7 @@ int rt_add_sprite(rt_scene *s, int geometry, int material, const double M[16]) {
 
 int rt_scene_commit(rt_scene *s, int device) {
     if (!s) return fail(RT_ERR_INVALID, "null scene");
+    std::lock_guard<std::mutex> recording_lock(s->mu);
     if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
     std::string err;
     int rc = rt::flatten_scene(s->ir, &s->flat, &err);
@@ -317,16 +337,37 @@ static unsigned kernel_features(const rt_scene *s) {
     if (s->flat.feature_mask & RT_FEAT_GENERAL) f |= 1u;
     if (s->flat.feature_mask & RT_FEAT_MEDIUM) f |= 2u;
     if (s->flat.feature_mask & RT_FEAT_TEXTURED) f |= 4u;
-    if (s->flat.feature_mask & RT_FEAT_MEDIUM_GENERAL) f |= 8u;
+    if (s->flat.feature_mask & (RT_FEAT_MEDIUM_GENERAL | RT_FEAT_DEEP_CHAIN)) f |= 8u; // + 2: that family is compiled with media
+    if (s->flat.feature_mask & RT_FEAT_DEEP_CHAIN) f |= 2u | 4u;
     if (s->flat.wide) f |= 1u; // 32-bit references exist in the general kernel families only
     return f;
 }
 
-// bytes of per-sample workspace a render may use; more samples are rendered in several passes
-static size_t sample_workspace_cap() {
+// bytes of per-sample workspace ONE render slot of this scene may hold; more samples are rendered in several passes.
+// rt_scene_set_workspace_limit, else RT_SAMPLE_WORKSPACE_MB, else the smaller of 32 GiB and a quarter of the device's memory
+// (an MI355X has 288 GB: 32 GiB; the headline 1200x800x500 render needs 15.36 GB and runs in one pass).  The workspace is
+// allocated at the size a render needs (never the cap), grows on demand, is reused by later renders and is given back by
+// rt_scene_trim / rt_scene_destroy.
+static size_t sample_workspace_cap(const rt_scene *s) {
+    if (s->workspace_limit) return s->workspace_limit;
     const char *e = std::getenv("RT_SAMPLE_WORKSPACE_MB");
     if (e && *e) return (size_t)std::strtoull(e, nullptr, 10) << 20;
-    return (size_t)32 << 30; // 32 GiB of the 288 GB
+    size_t cap = (size_t)32 << 30, free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b / 4 < cap) cap = total_b / 4;
+    return cap;
+}
+
+// the device error word of a slot (rt_lds.h RT_DEV_*): read, cleared, turned into RT_ERR_DEVICE.  The slot's work has finished.
+static int check_device_status(rt_scene::RenderSlot &sl) {
+    if (!sl.d_job_counter) return RT_OK;
+    unsigned st = 0;
+    HIP_TRY(hipMemcpy(&st, (const unsigned *)sl.d_job_counter + 16, sizeof st, hipMemcpyDeviceToHost));
+    if (st == RT_DEV_OK) return RT_OK;
+    (void)hipMemset((unsigned *)sl.d_job_counter + 16, 0, sizeof st);
+    std::string what;
+    if (st & RT_DEV_ERR_LDS_LAYOUT) what += " render_kernel was launched with fewer LDS bytes than its layout needs (rt_lds.h) and refused to run;";
+    if (st & RT_DEV_ERR_WATCHDOG) what += " a wave made no progress within its trip bound (counting build watchdog);";
+    return fail(RT_ERR_DEVICE, "device error word " + std::to_string(st) + ":" + what + " the image is incomplete");
 }
 
 // Render samples [s_begin, s_end) of every owned pixel.  accumulate: the tile buffer already holds the
@@ -358,13 +399,16 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     // pass size: as many samples per pixel as the workspace cap allows (32-byte record per sample)
     const size_t bytes_per_spp = (size_t)n_owned * RT_TILE_PIXELS * 4 * sizeof(double);
     const int n_spp = s_end - s_begin;
-    int chunk = (int)std::min<size_t>((size_t)n_spp, std::max<size_t>(1, sample_workspace_cap() / bytes_per_spp));
+    int chunk = (int)std::min<size_t>((size_t)n_spp, std::max<size_t>(1, sample_workspace_cap(s) / bytes_per_spp));
     // slot indices are 32-bit
     chunk = (int)std::min<size_t>((size_t)chunk, (size_t)0xFFFFFFFFu / ((size_t)n_owned * RT_TILE_PIXELS));
     if (chunk < 1) return fail(RT_ERR_INVALID, "image too large for one shard");
     const size_t need = bytes_per_spp * (size_t)chunk;
     if (!sl.done) HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-    if (!sl.d_job_counter) HIP_TRY(hipMalloc(&sl.d_job_counter, 256));
+    if (!sl.d_job_counter) { // word 0: the job counter (zeroed per launch); word 16: the device error word (sticky, rt_lds.h RT_DEV_*)
+        HIP_TRY(hipMalloc(&sl.d_job_counter, 256));
+        HIP_TRY(hipMemset(sl.d_job_counter, 0, 256));
+    }
     if (sl.used) HIP_TRY(hipStreamWaitEvent(st, sl.done, 0)); // the slot's previous render (any stream) has to be through
     if (need > sl.samples_bytes) {
         if (sl.d_samples) {
@@ -381,35 +425,34 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     const int lens = cam->lens_radius != 0.0;
     RtLaunch L;
     fill_launch(s, cam, p, n_owned, &L);
-    // dynamic LDS: the traversal stack, plus a copy of the node array when three workgroups
-    // of it still fit the CU's 160 KiB (book-one: 31 KB of nodes + 12 KB of stack)
+    // dynamic LDS (rt_lds.h: the one layout host and kernel share): the traversal stack, the waves' job state, a copy of the
+    // node array when the family's full occupancy still fits the CU's 160 KiB with it (book-one: 31 KB of nodes + 12 KB of
+    // stack), and the swap-at-shade queues with as many entries as are left (16 at least)
     const unsigned block = (unsigned)rt_kernel_block_size(feat);
     const int wide = s->flat.wide ? 1 : 0;
-    // traversal stack + the waves' job state (rt_kernels.hip: job_mem)
-    const unsigned stack_bytes = (unsigned)L.stack_entries * block * rt_stack_entry_bytes(wide) + rt_job_lds_bytes(feat);
+    const unsigned entry_bytes = wide ? 8u : 4u;
     const unsigned node_bytes = (unsigned)(s->flat.nodes.size() * sizeof(RtNode));
     const char *no_lds = std::getenv("RT_NO_LDS_NODES");
-    // swap-at-shade queues (rt_kernels.hip); RT_SWAP=0 selects the kernels without them (A/B runs)
+    // RT_SWAP=0 selects the kernels without the queues (A/B runs)
     const char *swap_env = std::getenv("RT_SWAP");
     const int swap = !(swap_env && *swap_env == '0');
-    // keep the kernel family's full occupancy resident: that many workgroups per CU, each with its own stack, node
-    // copy (when it fits) and swap queues (as many entries as fit, 16 at least)
+    // keep the kernel family's full occupancy resident: that many workgroups per CU share its LDS
     const unsigned groups_per_cu = std::max(1u, (unsigned)rt_kernel_waves_per_simd(feat) * 256u / block);
-    const unsigned lds_share = (160u * 1024u / groups_per_cu) & ~511u; // LDS is handed out in 512-byte granules
-    auto swap_cap_that_fits = [&](unsigned other) -> unsigned {
-        if (!swap) return 0u;
-        const unsigned per_entry = rt_swap_lds_bytes(2) - rt_swap_lds_bytes(1), hdr = rt_swap_lds_bytes(1) - per_entry;
-        if (block >= 512u) return rt_swap_cap_max(); // compiled in for the 512-thread families
-        if (other + hdr + 16u * per_entry > lds_share) return 16u; // does not fit anyway: fewer groups will be resident
-        return std::min(rt_swap_cap_max(), (lds_share - other - hdr) / per_entry);
-    };
+    const unsigned lds_share = (RT_LDS_PER_CU / groups_per_cu) & ~(RT_LDS_GRANULE - 1u);
     const int list = s->flat.n_list > 0; // the box list (< 1 KB) always lives in LDS
-    const int ldsnodes = list || (!wide && node_bytes > 0 && stack_bytes + node_bytes + (swap ? rt_swap_lds_bytes(block >= 512u ? 0u : 32u) : 0u) <= lds_share &&
-                                  !(no_lds && *no_lds == '1'));
-    const unsigned swap_cap = swap_cap_that_fits(stack_bytes + (ldsnodes ? node_bytes : 0u));
-    const unsigned swap_bytes = swap ? rt_swap_lds_bytes(swap_cap) : 0u;
+    const unsigned min_cap = swap ? (block >= 512u ? (unsigned)RT_SWAP_CAP : 32u) : 0u; // the node copy must leave room for this
+    const int ldsnodes = list || (!wide && node_bytes > 0 && !(no_lds && *no_lds == '1') &&
+                                  rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, node_bytes, min_cap).total <= lds_share);
+    const unsigned in_lds = ldsnodes ? node_bytes : 0u;
+    const unsigned swap_cap = swap ? rt_swap_cap_that_fits((unsigned)L.stack_entries, block, entry_bytes, in_lds, groups_per_cu) : 0u;
     L.swap_cap = (int)swap_cap;
-    const unsigned lds_bytes = stack_bytes + (ldsnodes ? node_bytes : 0u) + swap_bytes;
+    const RtLdsLayout lay = rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, in_lds, swap ? rt_swap_cap_effective(block, swap_cap) : 0u);
+    if (!rt_lds_layout_aligned(lay)) return fail(RT_ERR_DEVICE, "internal: misaligned LDS layout");
+    const unsigned lds_bytes = lay.total;
+    if (lds_bytes > RT_LDS_PER_CU) return fail(RT_ERR_UNSUPPORTED, "the scene's traversal stack does not fit a CU's LDS");
+    L.lds_bytes = lds_bytes;
+    if (const char *t = std::getenv("RT_TEST_LDS_SHORT")) // tests only: claim fewer bytes than the layout needs -> the kernel must refuse
+        if (*t == '1') L.lds_bytes = lds_bytes - 64u;
     const int lds_mode = (ldsnodes ? 1 : 0) | (swap ? 2 : 0) | (wide ? 4 : 0) | (list ? 8 : 0);
     int per_cu = 0, n_cu = 0, rc = 0;
     const unsigned occ_key = feat | (lens ? 16u : 0u) | (count ? 32u : 0u) | ((unsigned)lds_mode << 6); // feat uses bits 0-3
@@ -429,6 +472,15 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     }
     L.samples = (double *)sl.d_samples;
     L.job_counter = (unsigned int *)sl.d_job_counter;
+    L.status = (unsigned int *)sl.d_job_counter + 16;
+    // counting build: a wave may go this many times round its loop without finishing or starting a segment.  Every trip
+    // advances >= 1 of 64 lanes by one step of a traversal of <= nodes + prims steps, or drains a queue: 1024 x that is far
+    // beyond anything a healthy launch does (book-one: < 100 trips between two shade blocks)
+    L.watchdog_trips = 0u;
+    if (count) {
+        L.watchdog_trips = 1024u * (unsigned)(s->flat.nodes.size() + s->flat.prim_meta.size() + 64u);
+        if (const char *t = std::getenv("RT_TEST_WATCHDOG_TRIPS")) L.watchdog_trips = (unsigned)std::strtoul(t, nullptr, 10); // tests only
+    }
     L.counters = count ? (RtCounters *)d_counters : nullptr;
     const int n_pass = (n_spp + chunk - 1) / chunk;
     int last_blocks = 0;
@@ -503,18 +555,7 @@ int rt_render_progressive(rt_scene *s, const rt_camera *cam, const rt_render_par
     if (n_owned <= 0) return n_owned;
     const size_t n_doubles = (size_t)n_owned * RT_TILE_PIXELS * 3;
     std::vector<double> host(n_doubles, 0.0);
-    const int tx_n = tiles_x_of(p->width);
-    auto each_pixel = [&](auto &&f) { // f(index into host, index into sums)
-        for (int k = 0; k < n_owned; ++k) {
-            const int tile = p->shard_index + k * p->shard_count;
-            const int tx = tile % tx_n, ty = tile / tx_n;
-            for (int lane = 0; lane < RT_TILE_PIXELS; ++lane) {
-                const int x = tx * RT_TILE + (lane & 7), y = ty * RT_TILE + (lane >> 3);
-                if (x >= p->width || y >= p->height) continue;
-                f(((size_t)k * RT_TILE_PIXELS + (size_t)lane) * 3, ((size_t)y * (size_t)p->width + (size_t)x) * 3);
-            }
-        }
-    };
+    auto each_pixel = [&](auto &&f) { for_each_shard_pixel(p->width, p->height, p->shard_index, p->shard_count, n_owned, f); };
     const bool accumulate = s_begin > 0;
     if (accumulate) each_pixel([&](size_t h, size_t g) {
         host[h] = sums[g];
@@ -530,6 +571,10 @@ int rt_render_progressive(rt_scene *s, const rt_camera *cam, const rt_render_par
     q.flags &= ~RT_FLAG_COUNTERS;
     if (rc == RT_OK) rc = render_range(s, cam, &q, s_begin, s_end, accumulate, false, d_out, nullptr, nullptr);
     if (rc == RT_OK && (e = hipStreamSynchronize(nullptr)) != hipSuccess) rc = hip_fail(e, "render_kernel execution");
+    if (rc == RT_OK) {
+        std::lock_guard<std::mutex> lock(s->mu);
+        rc = check_device_status(s->slots[s->last_slot]);
+    }
     if (rc == RT_OK && (e = hipMemcpy(host.data(), d_out, n_doubles * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess)
         rc = hip_fail(e, "sums download");
     (void)hipFree(d_out);
@@ -556,7 +601,50 @@ int rt_last_kernel_ms(rt_scene *s, float *ms) {
         total += t;
     }
     *ms = total;
+    if (sl.used && hipEventQuery(sl.done) == hipSuccess)
+        if (int e = check_device_status(const_cast<rt_scene::RenderSlot &>(sl))) return e;
     return RT_OK;
+}
+
+int rt_render_status(rt_scene *s) {
+    if (!s) return fail(RT_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (s->device < 0) return RT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    int rc = RT_OK;
+    for (rt_scene::RenderSlot &sl : s->slots) {
+        if (!sl.used) continue;
+        HIP_TRY(hipEventSynchronize(sl.done));
+        if (int e = check_device_status(sl)) rc = e;
+    }
+    return rc;
+}
+
+int rt_scene_set_workspace_limit(rt_scene *s, size_t bytes) {
+    if (!s) return fail(RT_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
+    s->workspace_limit = bytes;
+    return RT_OK;
+}
+
+int rt_scene_trim(rt_scene *s) {
+    if (!s) return fail(RT_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> render_lock(s->render_mu);
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (s->device < 0) return RT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    for (rt_scene::RenderSlot &sl : s->slots) {
+        if (sl.used) HIP_TRY(hipEventSynchronize(sl.done)); // a render in flight still writes its workspace
+        if (sl.d_samples) HIP_TRY(hipFree(sl.d_samples));
+        sl.d_samples = nullptr;
+        sl.samples_bytes = 0;
+    }
+    return RT_OK;
+}
+
+size_t rt_scene_workspace_bytes(const rt_scene *s) {
+    if (!s) return 0;
+    return s->slots[0].samples_bytes + s->slots[1].samples_bytes;
 }
 
 int rt_last_launch_config(rt_scene *s, rt_launch_config *out) {
@@ -594,6 +682,10 @@ int rt_render(rt_scene *s, const rt_camera *cam, const rt_render_params *p, doub
     if (rc == RT_OK) {
         hipError_t e = hipStreamSynchronize(nullptr);
         if (e != hipSuccess) rc = hip_fail(e, "render_kernel execution");
+    }
+    if (rc == RT_OK) {
+        std::lock_guard<std::mutex> lock(s->mu);
+        rc = check_device_status(s->slots[s->last_slot]);
     }
     if (rc == RT_OK) {
         hipError_t e = hipMemcpy(host.data(), d_out, n_doubles * sizeof(double), hipMemcpyDeviceToHost);
@@ -636,20 +728,11 @@ int rt_render(rt_scene *s, const rt_camera *cam, const rt_render_params *p, doub
     if (d_cnt) (void)hipFree(d_cnt);
     if (rc != RT_OK) return rc;
     // scatter the packed tiles into the caller's [y][x][3] image
-    const int tx_n = tiles_x_of(p->width);
-    for (int k = 0; k < n_owned; ++k) {
-        const int tile = p->shard_index + k * p->shard_count;
-        const int tx = tile % tx_n, ty = tile / tx_n;
-        for (int lane = 0; lane < RT_TILE_PIXELS; ++lane) {
-            const int x = tx * RT_TILE + (lane & 7), y = ty * RT_TILE + (lane >> 3);
-            if (x >= p->width || y >= p->height) continue;
-            const double *src = &host[((size_t)k * RT_TILE_PIXELS + (size_t)lane) * 3];
-            double *dst = out_rgb + ((size_t)y * (size_t)p->width + (size_t)x) * 3;
-            dst[0] = src[0];
-            dst[1] = src[1];
-            dst[2] = src[2];
-        }
-    }
+    for_each_shard_pixel(p->width, p->height, p->shard_index, p->shard_count, n_owned, [&](size_t t, size_t g) {
+        out_rgb[g] = host[t];
+        out_rgb[g + 1] = host[t + 1];
+        out_rgb[g + 2] = host[t + 2];
+    });
     return RT_OK;
 }
 
@@ -659,8 +742,13 @@ rt_scene *rt_scene_clone(const rt_scene *src, int device) {
         return nullptr;
     }
     rt_scene *s = new rt_scene;
-    s->ir = src->ir;
-    if (src->committed && rt_scene_commit(s, device) != RT_OK) { // g_err is set
+    bool committed;
+    {
+        std::lock_guard<std::mutex> lock(const_cast<rt_scene *>(src)->mu); // rt_add_* on the source take it too
+        s->ir = src->ir;
+        committed = src->committed;
+    }
+    if (committed && rt_scene_commit(s, device) != RT_OK) { // g_err is set
         rt_scene_destroy(s);
         return nullptr;
     }
@@ -685,6 +773,36 @@ int rt_render_sharded(rt_scene *const *scenes, int n, const rt_camera *cam, cons
     for (std::thread &t : workers) t.join();
     for (int i = 0; i < n; ++i)
         if (rc[(size_t)i] != RT_OK) return fail(rc[(size_t)i], "shard " + std::to_string(i) + ": " + msg[(size_t)i]);
+    return RT_OK;
+}
+
+int rt_pack_tiles_host(const double *image, int width, int height, int shard_index, int shard_count, int tiles_padded, double *tiles_out) {
+    if (!image || !tiles_out) return fail(RT_ERR_INVALID, "null argument");
+    const int n_owned = rt_shard_tile_count(width, height, shard_index, shard_count);
+    if (n_owned < 0) return n_owned;
+    if (tiles_padded < n_owned) return fail(RT_ERR_INVALID, "tiles_padded is smaller than the shard's tile count");
+    std::fill(tiles_out, tiles_out + (size_t)tiles_padded * RT_TILE_PIXELS * 3, 0.0);
+    for_each_shard_pixel(width, height, shard_index, shard_count, n_owned, [&](size_t t, size_t g) {
+        tiles_out[t] = image[g];
+        tiles_out[t + 1] = image[g + 1];
+        tiles_out[t + 2] = image[g + 2];
+    });
+    return RT_OK;
+}
+
+int rt_unpack_tiles_host(const double *gathered, int tiles_per_shard_padded, int shard_count, int width, int height, double *image_out) {
+    if (!gathered || !image_out || tiles_per_shard_padded <= 0 || shard_count <= 0 || width <= 0 || height <= 0)
+        return fail(RT_ERR_INVALID, "bad argument");
+    for (int r = 0; r < shard_count; ++r) {
+        const int n_owned = rt_shard_tile_count(width, height, r, shard_count);
+        if (n_owned > tiles_per_shard_padded) return fail(RT_ERR_INVALID, "tiles_per_shard_padded is smaller than a shard's tile count");
+        const double *src = gathered + (size_t)r * (size_t)tiles_per_shard_padded * RT_TILE_PIXELS * 3;
+        for_each_shard_pixel(width, height, r, shard_count, n_owned, [&](size_t t, size_t g) {
+            image_out[g] = src[t];
+            image_out[g + 1] = src[t + 1];
+            image_out[g + 2] = src[t + 2];
+        });
+    }
     return RT_OK;
 }
 

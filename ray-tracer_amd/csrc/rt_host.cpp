@@ -496,7 +496,7 @@ struct Flattener {
 
     void finish_meta(RtPrimMeta *m, const std::vector<Link> &chain) {
         uint32_t tmask = 0;
-        for (size_t i = 0; i < chain.size(); ++i)
+        for (size_t i = 0; i < chain.size() && i < (size_t)RT_MAX_CHAIN; ++i) // deeper levels always take the full 4x4 form
             if (chain[i].translation) tmask |= 1u << i;
         m->kind = (m->kind & 0xFFu) | ((uint32_t)chain.size() << RT_META_CHAIN_SHIFT) | (tmask << RT_META_TMASK_SHIFT);
     }
@@ -514,8 +514,11 @@ struct Flattener {
             std::vector<Shape> shapes;
             if (!collect_shapes(gi, chain, &shapes, depth)) return false;
             for (const Shape &sh : shapes) {
-                if (sh.chain.size() > RT_MAX_CHAIN)
-                    return fail(RT_ERR_UNSUPPORTED, "more than RT_MAX_CHAIN (4) transform levels above one primitive");
+                if (sh.chain.size() > RT_MAX_CHAIN_DEEP)
+                    return fail(RT_ERR_UNSUPPORTED, "more than RT_MAX_CHAIN_DEEP (15) transform levels above one primitive");
+                // more than four levels (src/sprite.rs:87-93 nests without bound): the kernel family that walks chains of any
+                // length, slower (the one for media over general boundaries)
+                if (sh.chain.size() > RT_MAX_CHAIN) fs.feature_mask |= RT_FEAT_GENERAL | RT_FEAT_DEEP_CHAIN;
                 Leaf lf;
                 lf.meta.material = material;
                 lf.chain = sh.chain;
@@ -559,8 +562,9 @@ struct Flattener {
             }
             return true;
         case GEO_MEDIUM: {
-            if (chain.size() > RT_MAX_CHAIN)
-                return fail(RT_ERR_UNSUPPORTED, "more than RT_MAX_CHAIN (4) transform levels above one primitive");
+            if (chain.size() > RT_MAX_CHAIN_DEEP)
+                return fail(RT_ERR_UNSUPPORTED, "more than RT_MAX_CHAIN_DEEP (15) transform levels above one primitive");
+            if (chain.size() > RT_MAX_CHAIN) fs.feature_mask |= RT_FEAT_GENERAL | RT_FEAT_DEEP_CHAIN;
             Leaf lf;
             lf.meta.material = material;
             lf.chain = chain;
@@ -586,8 +590,8 @@ struct Flattener {
                 if (!collect_shapes(g.boundary, {}, &lf.boundary, depth + 1)) return false;
                 bool first = true;
                 for (const Shape &sh : lf.boundary) {
-                    if (sh.chain.size() > RT_MAX_CHAIN)
-                        return fail(RT_ERR_UNSUPPORTED, "more than RT_MAX_CHAIN (4) transform levels inside a medium's boundary");
+                    if (sh.chain.size() > RT_MAX_CHAIN_DEEP)
+                        return fail(RT_ERR_UNSUPPORTED, "more than RT_MAX_CHAIN_DEEP (15) transform levels inside a medium's boundary");
                     const Aabb sb = chain_bound(shape_local_bound(sh), chain, sh.chain);
                     lf.bound = first ? sb : merged(lf.bound, sb);
                     first = false;

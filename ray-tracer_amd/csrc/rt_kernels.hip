@@ -39,6 +39,7 @@
 #include <hip/hip_runtime.h>
 
 #include "rt_lane.h"
+#include "rt_lds.h"
 #include "rt_types.h"
 
 // The library is built from TWO compilations of this file (Makefile): part 1 holds the spheres-only and the lean general
@@ -116,9 +117,7 @@
 // class into its free lanes, so Material::scatter runs on (nearly) homogeneous lanes; new samples are started in
 // bulk the same way ("new" mode).  Nothing ever waits: a busy queue lock or a full queue just means the lane is
 // shaded in place.  Which lane or wave finishes a path cannot change its result (per-sample streams and records).
-#ifndef RT_SWAP_CAP
-#define RT_SWAP_CAP 64 /* entries per class queue at most; fewer when four 256-thread groups have to share a CU's LDS */
-#endif
+// (RT_SWAP_CAP and the entry layout: rt_lds.h)
 #ifndef RT_SWAP_MODE_MIN
 #define RT_SWAP_MODE_MIN 56 /* a class needs this many lanes (own + parked) to be chosen over starting new samples */
 #endif
@@ -140,11 +139,6 @@
 #ifndef RT_SWAP_LOCK_TRIES
 #define RT_SWAP_LOCK_TRIES 8
 #endif
-#define RT_SWAP_CLASSES 3  /* lambertian, metal, dielectric (RT_MAT_* values 0..2) */
-#define RT_SWAP_F64 14     /* o, d, T (9), s0, s1, best_t, draws, base */
-#define RT_SWAP_F32 3      /* k, best_prim, slot */
-#define RT_SWAP_HDR_BYTES 32u
-#define RT_SWAP_ENTRY_BYTES ((unsigned)(RT_SWAP_F64 * 8 + RT_SWAP_F32 * 4))
 
 namespace {
 
@@ -268,23 +262,31 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
     // entries per class queue: the most (<= RT_SWAP_CAP) that leaves the kernel family's full occupancy resident (host)
     // (a compile-time constant for the 512-thread families: the address arithmetic of a run-time capacity costs the
     // book-one kernel 2 %)
-    const uint32_t kSwapCap = kBlock >= 512 ? (uint32_t)RT_SWAP_CAP : (uint32_t)L.swap_cap, kSwapClassBytes = RT_SWAP_ENTRY_BYTES * kSwapCap;
+    const uint32_t kSwapCap = SWAP ? rt_swap_cap_effective((uint32_t)kBlock, (uint32_t)L.swap_cap) : 0u;
     Stack st;
     st.set(rt_lds);
-    constexpr size_t kStackEntry = Stack::kEntryBytes;
+    constexpr uint32_t kStackEntry = Stack::kEntryBytes;
     const RtNode *nodes = L.nodes;
-    const unsigned node_lds_bytes = LDSNODES ? (unsigned)L.n_nodes * (unsigned)sizeof(RtNode) : 0u;
+    const uint32_t node_lds_bytes = LDSNODES ? (uint32_t)L.n_nodes * (uint32_t)sizeof(RtNode) : 0u;
+    // ONE layout function for host and device (rt_lds.h); a launch that provides fewer bytes than it needs is refused
+    // instead of run: every wave returns at once and the host reports RT_ERR_DEVICE
+    const RtLdsLayout lay = rt_lds_layout((uint32_t)L.stack_entries, (uint32_t)kBlock, kStackEntry, node_lds_bytes, kSwapCap);
+    const uint32_t kSwapClassBytes = lay.swap_class_bytes;
+    if (lay.total > L.lds_bytes) { // wave-uniform (kernel arguments only)
+        if (threadIdx.x == 0u) atomicOr(L.status, RT_DEV_ERR_LDS_LAYOUT);
+        return;
+    }
     // swap queues: header {state[3], pad...}: state = entries in the queue | kSwapLock while a wave works on it; then per class RT_SWAP_F64 arrays of CAP doubles and
     // RT_SWAP_F32 arrays of CAP words (field-major: consecutive entries are consecutive addresses)
     // per-wave job state (8 words per wave): it only changes in the refill step, and as loop-carried registers its seven
     // words were copied out and back on every trip round the vote loop (25 v_mov per node-block visit)
-    uint32_t *job_mem = reinterpret_cast<uint32_t *>(rt_lds + (size_t)L.stack_entries * kBlock * kStackEntry + node_lds_bytes) + (threadIdx.x >> 6) * 8u;
+    uint32_t *job_mem = reinterpret_cast<uint32_t *>(rt_lds + lay.job_off) + (threadIdx.x >> 6) * (RT_JOB_BYTES_PER_WAVE / 4u);
     if ((threadIdx.x & 63u) < 8u) job_mem[threadIdx.x & 63u] = (threadIdx.x & 63u) == 6u ? 1u : 0u; // job_nspp = 1, the rest 0
-    unsigned char *swap_mem = rt_lds + (size_t)L.stack_entries * kBlock * kStackEntry + node_lds_bytes + (kBlock / 64) * 32;
+    unsigned char *swap_mem = rt_lds + lay.swap_off;
     uint32_t *swap_hdr = reinterpret_cast<uint32_t *>(swap_mem);
     if (SWAP && threadIdx.x < RT_SWAP_HDR_BYTES / 4u) swap_hdr[threadIdx.x] = 0u;
     if (LDSNODES) {
-        uint4 *dst = reinterpret_cast<uint4 *>(rt_lds + (size_t)L.stack_entries * kBlock * kStackEntry);
+        uint4 *dst = reinterpret_cast<uint4 *>(rt_lds + lay.node_off);
         const uint4 *src = reinterpret_cast<const uint4 *>(L.nodes);
         const int n16 = L.n_nodes * (int)(sizeof(RtNode) / 16);
         for (int i = (int)threadIdx.x; i < n16; i += kBlock) dst[i] = src[i];
@@ -310,8 +312,17 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
     unsigned long long w_class = 0, w_new = 0, w_park = 0, w_pull = 0, w_busy = 0, w_scat = 0, w_off = 0, t_swap = 0; // swap diagnostics
 #define RT_STAMP(v) do { if (COUNT) v = __builtin_amdgcn_s_memtime(); } while (0)
     const bool counting_lane = COUNT && (threadIdx.x & 63) == 0;
+    // Counting build only: a wave that goes round its loop `watchdog_trips` times without finishing or starting one segment is
+    // not going to (every trip advances at least one lane by one step of a finite traversal, or drains a queue): it sets the
+    // device error word and leaves, so a livelock -- the only failure a persistent kernel cannot report otherwise -- comes
+    // back as RT_ERR_DEVICE.  Wave-uniform by construction (incremented and reset on wave-uniform conditions).
+    uint32_t wd_trips = 0u;
 
     for (;;) {
+        if (COUNT && L.watchdog_trips != 0u && ++wd_trips > L.watchdog_trips) {
+            if ((threadIdx.x & 63u) == 0u) atomicOr(L.status, RT_DEV_ERR_WATCHDOG);
+            break;
+        }
         const bool is_done = tv.cur == Ref::kDone;
         const bool is_leaf = tv.cur >= Ref::kLeaf && tv.cur < Ref::kDone;
         const bool is_node = tv.cur < Ref::kLeaf;
@@ -660,6 +671,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                 else // SWAP: an empty lane waits (DONE, no path) for a parked path or the next bulk refill
                     tv.cur = (!SWAP || queue_empty) ? Ref::kDead : Ref::kDone;
             }
+            if (COUNT && __ballot(part && !pending) != 0ull) wd_trips = 0u; // a segment was finished, begun, or a lane retired
             RT_STAMP(t1);
             t_beg += t1 - t0;
         } else if (nL >= kVoteLeaf || nN == 0) {
@@ -897,14 +909,6 @@ extern "C" int rt_kernel_waves_per_simd(unsigned features) {
     return features == 0u ? RT_WAVES_PER_EU
                           : (features == 1u ? RT_WAVES_PER_EU_LEAN : ((features & 8u) ? RT_WAVES_PER_EU_GENERAL : RT_WAVES_PER_EU_MEDIUM));
 }
-// dynamic LDS of the swap queues with `cap` entries per class; cap = 0 asks for the largest capacity
-extern "C" unsigned rt_swap_lds_bytes(unsigned cap) {
-    return RT_SWAP_HDR_BYTES + RT_SWAP_CLASSES * RT_SWAP_ENTRY_BYTES * (cap ? cap : (unsigned)RT_SWAP_CAP);
-}
-extern "C" unsigned rt_swap_cap_max(void) { return RT_SWAP_CAP; }
-extern "C" unsigned rt_stack_entry_bytes(int wide) { return wide ? 8u : 4u; }
-extern "C" unsigned rt_job_lds_bytes(unsigned features) { return (unsigned)(rt_kernel_block_size(features) / 64) * 32u; }
-
 // occupancy-derived size of the persistent grid
 extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int ldsnodes, unsigned lds_bytes, int *blocks_per_cu,
                                     int *n_cu) {

@@ -411,6 +411,7 @@ struct SegCtx { // what a primitive test may need besides the ray
 // M^-1 (o,1) = o + inv_t, M^-1 (d,0) = d, M (p,1) = p + t, M (n,0) = n -- the values the 4x4 products give for it.
 // (constant trip counts: the compiler unrolls them, and a level the wave does not have is one skipped branch; a
 // data-dependent loop here made it keep the hit record in scratch memory)
+template <bool DEEP = false>
 RT_HD void chain_down(const RtLaunch &L, uint32_t first, uint32_t len, uint32_t tmask, V3 *o, V3 *d) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -426,8 +427,20 @@ RT_HD void chain_down(const RtLaunch &L, uint32_t first, uint32_t len, uint32_t 
             *o = lo;
         }
     }
+    // levels beyond the four unrolled ones (only the kernel family for general media / deep chains is compiled with them):
+    // always the full 4x4 products, the reference's own form (src/sprite.rs:101-106)
+    if (DEEP)
+        for (uint32_t i = (uint32_t)RT_MAX_CHAIN; i < len; ++i) {
+            const RtXform &X = L.xforms[first + i];
+            const V3 lo = xf_point(X.inv, *o);
+            *d = xf_vector(X.inv, *d);
+            *o = lo;
+        }
 }
+template <bool DEEP = false>
 RT_HD void chain_up(const RtLaunch &L, uint32_t first, uint32_t len, uint32_t tmask, Rec *r) {
+    if (DEEP)
+        for (uint32_t i = len; i > (uint32_t)RT_MAX_CHAIN; --i) to_world(L.xforms[first + i - 1u], r);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -442,7 +455,10 @@ RT_HD void chain_up(const RtLaunch &L, uint32_t first, uint32_t len, uint32_t tm
     }
 }
 
+template <bool DEEP = false>
 RT_HD void chain_up_point(const RtLaunch &L, uint32_t first, uint32_t len, uint32_t tmask, V3 *p) {
+    if (DEEP)
+        for (uint32_t i = len; i > (uint32_t)RT_MAX_CHAIN; --i) *p = xf_point(L.xforms[first + i - 1u].m, *p);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -486,13 +502,13 @@ RT_HD bool medium_general_hit(const RtLaunch &L, const RtPrimGeo &G, V3 o, V3 d,
         for (uint32_t k = 0; k < count; ++k) {
             const uint32_t ci = first + k;
             const uint32_t kw = L.prim_meta[ci].kind;
-            const uint32_t cf = L.prim_meta[ci].xform, cl = (kw >> RT_META_CHAIN_SHIFT) & 7u, cm = (kw >> RT_META_TMASK_SHIFT) & 0xFu;
+            const uint32_t cf = L.prim_meta[ci].xform, cl = (kw >> RT_META_CHAIN_SHIFT) & 0xFu, cm = (kw >> RT_META_TMASK_SHIFT) & 0xFu;
             V3 co = ro, cd = d;
-            chain_down(L, cf, cl, cm, &co, &cd);
+            chain_down<true>(L, cf, cl, cm, &co, &cd);
             Rec cr;
             ++*tests;
             if (shape_hit<true>(kw & 0xFFu, L.prim_geo[ci], co, cd, uv, &cr) && (!have || cr.t < best.t)) {
-                chain_up(L, cf, cl, cm, &cr);
+                chain_up<true>(L, cf, cl, cm, &cr);
                 best = cr;
                 have = true;
             }
@@ -565,16 +581,16 @@ RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx
             if (RECORD) r->p = r->p + c;
             return true;
         }
-        const uint32_t first = P.xform, len = (kw >> RT_META_CHAIN_SHIFT) & 7u, tmask = (kw >> RT_META_TMASK_SHIFT) & 0xFu;
+        const uint32_t first = P.xform, len = (kw >> RT_META_CHAIN_SHIFT) & 0xFu, tmask = (kw >> RT_META_TMASK_SHIFT) & 0xFu;
         V3 lo = o, ld = d;
-        chain_down(L, first, len, tmask, &lo, &ld);
+        chain_down<(MEDIUM >= 2)>(L, first, len, tmask, &lo, &ld);
         bool ok;
         if (MEDIUM >= 2 && kind == RT_PRIM_MEDIUM_C)
             ok = medium_general_hit(L, G, lo, ld, sc.rng_base, sc.segment, P.aux, &sc.draws, &sc.prims_tested, uv, r);
         else
             ok = shape_hit<RECORD>(kind, G, lo, ld, uv, r);
         if (!ok) return false;
-        if (RECORD) chain_up(L, first, len, tmask, r);
+        if (RECORD) chain_up<(MEDIUM >= 2)>(L, first, len, tmask, r);
         return true;
     }
     return false;
@@ -602,18 +618,18 @@ RT_HD void prim_record(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double t, Seg
             prim_hit<GENERAL, MEDIUM, true>(L, pi, o, d, dot(d, d), sc, r, false);
             return;
         }
-        const uint32_t first = L.prim_meta[pi].xform, len = (kw >> RT_META_CHAIN_SHIFT) & 7u, tmask = (kw >> RT_META_TMASK_SHIFT) & 0xFu;
+        const uint32_t first = L.prim_meta[pi].xform, len = (kw >> RT_META_CHAIN_SHIFT) & 0xFu, tmask = (kw >> RT_META_TMASK_SHIFT) & 0xFu;
         V3 lo = o, ld = d;
-        chain_down(L, first, len, tmask, &lo, &ld);
+        chain_down<(MEDIUM >= 2)>(L, first, len, tmask, &lo, &ld);
         if (kind == RT_PRIM_SPHERE_C) {
             sphere_finish(lo, ld, G.g[0], t, false, r);
-            chain_up(L, first, len, tmask, r);
+            chain_up<(MEDIUM >= 2)>(L, first, len, tmask, r);
         } else { // RT_PRIM_RECT_C: rect_hit's t, p (src/geometry.rs:160,176), the chain for the point, the leaf's normal
             r->t = t;
             r->u = 0.0;
             r->v = 0.0;
             r->p = lo + ld * t;
-            chain_up_point(L, first, len, tmask, &r->p);
+            chain_up_point<(MEDIUM >= 2)>(L, first, len, tmask, &r->p);
             r->n = mk(G.g[2], G.g[3], L.prim_extra[pi].e[0]);
         }
     }
@@ -981,7 +997,7 @@ RT_HD void prim_uv(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double t, SegCtx 
         }
         const RtPrimMeta &P = L.prim_meta[pi];
         V3 lo = o, ld = d;
-        chain_down(L, P.xform, (kw >> RT_META_CHAIN_SHIFT) & 7u, (kw >> RT_META_TMASK_SHIFT) & 0xFu, &lo, &ld);
+        chain_down<(MEDIUM >= 2)>(L, P.xform, (kw >> RT_META_CHAIN_SHIFT) & 0xFu, (kw >> RT_META_TMASK_SHIFT) & 0xFu, &lo, &ld);
         if (kind == RT_PRIM_SPHERE_C) {
             sphere_uv((lo + ld * t) / G.g[0], u, v);
         } else {

@@ -1,0 +1,88 @@
+// rt_lds.h -- THE layout of render_kernel's dynamic LDS, one definition for the host (rt_api.cpp sizes the launch with
+// it) and the device (rt_kernels.hip carves the regions out of it).
+//
+// Why it exists ("the 05:58 abort of round 2"): the kernel placed a new region (the waves' job state)
+// between the node copy and the swap queues while the host still sized the launch without it; the queues' last 128 bytes then
+// lay outside the workgroup's allocation and aliased the next workgroup's traversal stack -- a persistent kernel whose
+// waves only leave when their paths are finished turns that into a hang, not a wrong pixel.  With one function there is no
+// second place to forget; the kernel additionally refuses to run (error word -> RT_ERR_DEVICE) when the bytes it was
+// launched with are fewer than the layout needs.
+//
+//   [ traversal stack: stack_entries x block x entry_bytes ][ node copy or box list (optional) ][ job state: 32 B per wave ]
+//   [ swap header 32 B ][ class 0 | class 1 | class 2 : RT_SWAP_F64 arrays of cap doubles, then RT_SWAP_F32 arrays of cap words ]
+#ifndef RT_LDS_H
+#define RT_LDS_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define RT_LDS_HD __host__ __device__ inline
+#else
+#define RT_LDS_HD inline
+#endif
+
+#ifndef RT_SWAP_CAP
+#define RT_SWAP_CAP 64 /* entries per class queue at most; fewer when four 256-thread groups have to share a CU's LDS */
+#endif
+#define RT_SWAP_CLASSES 3  /* lambertian, metal, dielectric (RT_MAT_* values 0..2) */
+#define RT_SWAP_F64 14     /* o, d, T (9), s0, s1, best_t, draws, base */
+#define RT_SWAP_F32 3      /* k, best_prim, slot */
+#define RT_SWAP_HDR_BYTES 32u
+#define RT_SWAP_ENTRY_BYTES ((unsigned)(RT_SWAP_F64 * 8 + RT_SWAP_F32 * 4))
+#define RT_JOB_BYTES_PER_WAVE 32u
+#define RT_LDS_GRANULE 512u /* LDS is handed out in 512-byte granules */
+#define RT_LDS_PER_CU (160u * 1024u)
+
+struct RtLdsLayout {
+    uint32_t stack_off, node_off, job_off, swap_off; // byte offsets of the regions
+    uint32_t swap_class_bytes;                       // one class queue
+    uint32_t total;                                  // bytes the launch has to provide
+};
+
+// the capacity the kernel really uses: compiled in for the 512-thread family (run-time address arithmetic costs it 2 %),
+// the launch's value (EVEN: a class is 124 x cap bytes and its binary64 arrays have to stay 8-byte aligned) for the others
+RT_LDS_HD constexpr uint32_t rt_swap_cap_effective(uint32_t block_threads, uint32_t launch_cap) {
+    return block_threads >= 512u ? (uint32_t)RT_SWAP_CAP : (launch_cap & ~1u);
+}
+
+// node_bytes: 0 when the node array stays in global memory; swap_cap: 0 for the kernels without swap queues
+RT_LDS_HD constexpr RtLdsLayout rt_lds_layout(uint32_t stack_entries, uint32_t block_threads, uint32_t stack_entry_bytes, uint32_t node_bytes,
+                                              uint32_t swap_cap) {
+    RtLdsLayout l{};
+    l.stack_off = 0u;
+    l.node_off = stack_entries * block_threads * stack_entry_bytes; // multiple of 256: uint4 copies stay aligned
+    l.job_off = l.node_off + ((node_bytes + 15u) & ~15u);
+    l.swap_off = l.job_off + (block_threads / 64u) * RT_JOB_BYTES_PER_WAVE;
+    l.swap_class_bytes = RT_SWAP_ENTRY_BYTES * swap_cap;
+    l.total = l.swap_off + (swap_cap ? RT_SWAP_HDR_BYTES + (uint32_t)RT_SWAP_CLASSES * l.swap_class_bytes : 0u);
+    return l;
+}
+// every region starts where its widest access needs it to
+RT_LDS_HD constexpr bool rt_lds_layout_aligned(const RtLdsLayout &l) {
+    return l.node_off % 16u == 0u && l.job_off % 16u == 0u && l.swap_off % 8u == 0u && l.swap_class_bytes % 8u == 0u;
+}
+
+// The largest EVEN capacity (<= RT_SWAP_CAP) with which `groups_per_cu` workgroups of this shape still share one CU's LDS;
+// 16 when even that does not fit (fewer groups will be resident).
+RT_LDS_HD constexpr uint32_t rt_swap_cap_that_fits(uint32_t stack_entries, uint32_t block_threads, uint32_t stack_entry_bytes, uint32_t node_bytes,
+                                                   uint32_t groups_per_cu) {
+    if (block_threads >= 512u) return (uint32_t)RT_SWAP_CAP;
+    const uint32_t share = (RT_LDS_PER_CU / (groups_per_cu ? groups_per_cu : 1u)) & ~(RT_LDS_GRANULE - 1u);
+    const uint32_t other = rt_lds_layout(stack_entries, block_threads, stack_entry_bytes, node_bytes, 0u).total + RT_SWAP_HDR_BYTES;
+    const uint32_t per_entry = (uint32_t)RT_SWAP_CLASSES * RT_SWAP_ENTRY_BYTES;
+    if (other + 16u * per_entry > share) return 16u;
+    const uint32_t cap = (share - other) / per_entry;
+    return (cap < (uint32_t)RT_SWAP_CAP ? cap : (uint32_t)RT_SWAP_CAP) & ~1u;
+}
+
+static_assert(rt_lds_layout_aligned(rt_lds_layout(24, 512, 4, 31 * 1024, RT_SWAP_CAP)), "book-one shape");
+static_assert(rt_lds_layout_aligned(rt_lds_layout(17, 256, 4, 648, 38)), "list shape, even capacity");
+static_assert(rt_lds_layout_aligned(rt_lds_layout(13, 256, 8, 0, 16)), "wide references");
+static_assert(rt_lds_layout(10, 256, 4, 0, 0).total == 10 * 256 * 4 + 4 * RT_JOB_BYTES_PER_WAVE, "no queues: stack + job state");
+
+// device error word (RtLaunch::status): set by the kernel, turned into RT_ERR_DEVICE by the host
+#define RT_DEV_OK 0u
+#define RT_DEV_ERR_LDS_LAYOUT 1u /* launched with fewer LDS bytes than rt_lds_layout() needs */
+#define RT_DEV_ERR_WATCHDOG 2u   /* counting build: a wave went round its loop without finishing a segment for too long */
+
+#endif

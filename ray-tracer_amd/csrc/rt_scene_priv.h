@@ -20,6 +20,7 @@ struct rt_scene {
     void *d_nodes = nullptr, *d_prim_meta = nullptr, *d_prim_geo = nullptr, *d_prim_extra = nullptr, *d_xforms = nullptr,
          *d_materials = nullptr, *d_textures = nullptr, *d_blob = nullptr;
     size_t device_bytes = 0;
+    size_t workspace_limit = 0; // rt_scene_set_workspace_limit; 0 = default (rt_api.cpp sample_workspace_cap)
     std::mutex mu;        // guards the fields below
     std::mutex render_mu; // serialises rt_render calls: they share the sample workspace
     // cached occupancy query of the last kernel variant used

@@ -12,7 +12,8 @@
 #define RT_MAX_HOISTED 4    /* scene-filling prims tested up front instead of through the BVH */
 #define RT_LIST_MAX 24      /* general scenes of up to this many BVH leaves are walked as a box LIST (rtl::trav_list_step) */
 #define RT_LIST_BOX_FLOATS 9 /* one list box: {lo, hi, lo} per axis -- entry plane at [s], exit plane at [s + 1], s = sign bit of 1/d */
-#define RT_MAX_CHAIN 4      /* transform levels above one leaf (Sprite > BVH > Sprite > TransformedGeometry ...) */
+#define RT_MAX_CHAIN 4      /* transform levels above one leaf (Sprite > BVH > Sprite > TransformedGeometry ...) every kernel family unrolls */
+#define RT_MAX_CHAIN_DEEP 15 /* levels the family for general media / deep chains walks (the ones beyond RT_MAX_CHAIN in a run-time loop) */
 #define RT_JOB_SPP_MAX 32   /* samples per pixel in one job at most (job = one 8x8 tile x job_spp samples) */
 #define RT_NO_MATERIAL 0xFFFFFFFFu
 #define RT_MAT_KIND_NONE 0xFFu /* in RtPrimMeta::kind bits 8-15: the prim has no material */
@@ -51,8 +52,8 @@ enum RtPrimKind : uint32_t {
                           // the boundary's prims (spheres / rectangles with their own chains below the medium) follow the
                           // leaf prims in the prim arrays and are never BVH leaves
 };
-// RtPrimMeta::kind: bits 0-7 RT_PRIM_*, bits 8-15 kind of the material (RT_MAT_*, RT_MAT_KIND_NONE), bits 16-18 chain
-// length, bits 20-23 one bit per chain level: that level is a pure translation (only its offset is used:
+// RtPrimMeta::kind: bits 0-7 RT_PRIM_*, bits 8-15 kind of the material (RT_MAT_*, RT_MAT_KIND_NONE), bits 16-19 chain
+// length, bits 20-23 one bit per level of the first RT_MAX_CHAIN: that level is a pure translation (only its offset is used:
 // o' = o + inv_t, d' = d, p = p' + t, n = n' -- what the 4x4 products give for such a matrix, rounding for rounding)
 #define RT_META_CHAIN_SHIFT 16
 #define RT_META_TMASK_SHIFT 20
@@ -158,6 +159,9 @@ struct RtLaunch {
     // this pass: samples [s0, s0 + s_count) of every owned pixel
     int32_t s0, s_count;
     int32_t job_spp, jobs_per_tile, n_jobs; // job_spp adapts so that every wave sees >= ~32 jobs
+    uint32_t lds_bytes;        // dynamic LDS this launch provides: the kernel checks it against rt_lds_layout() (rt_lds.h)
+    uint32_t watchdog_trips;   // counting build: loop trips a wave may make without finishing or starting a segment (0 = no bound)
+    unsigned int *status;      // device error word (RT_DEV_*), sticky until the host reads it
     unsigned int *job_counter; // zeroed before the launch
     double *samples;           // per-sample radiance of this pass: [owned tile][s - s0][pixel][4] (32-byte records)
     RtCounters *counters;      // may be null

@@ -296,6 +296,12 @@ class BoundingVolumeHierarchyNode {
         check(rt_scene_hash(scene_.get(), &h));
         return h;
     }
+    // the per-sample workspace the renders keep on the device: its limit per render slot (0 = default), its release, its size
+    void set_workspace_limit(size_t bytes) const { check(rt_scene_set_workspace_limit(scene_.get(), bytes)); }
+    void trim() const { check(rt_scene_trim(scene_.get())); }
+    size_t workspace_bytes() const { return rt_scene_workspace_bytes(scene_.get()); }
+    // waits for the renders launched on this world; throws when a kernel reported a device error word
+    void status() const { check(rt_render_status(scene_.get())); }
     rt_scene_info info() const {
         rt_scene_info i;
         check(rt_scene_get_info(scene_.get(), &i));

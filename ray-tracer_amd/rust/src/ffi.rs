@@ -194,6 +194,27 @@ extern "C" {
         d_image_out: *mut c_void,
         stream: *mut c_void,
     ) -> c_int;
+    pub fn rt_pack_tiles_host(
+        image: *const c_double,
+        width: c_int,
+        height: c_int,
+        shard_index: c_int,
+        shard_count: c_int,
+        tiles_padded: c_int,
+        tiles_out: *mut c_double,
+    ) -> c_int;
+    pub fn rt_unpack_tiles_host(
+        gathered: *const c_double,
+        tiles_per_shard_padded: c_int,
+        shard_count: c_int,
+        width: c_int,
+        height: c_int,
+        image_out: *mut c_double,
+    ) -> c_int;
+    pub fn rt_render_status(s: *mut rt_scene) -> c_int;
+    pub fn rt_scene_set_workspace_limit(s: *mut rt_scene, bytes: usize) -> c_int;
+    pub fn rt_scene_trim(s: *mut rt_scene) -> c_int;
+    pub fn rt_scene_workspace_bytes(s: *const rt_scene) -> usize;
     pub fn rt_last_kernel_ms(s: *mut rt_scene, ms: *mut c_float) -> c_int;
     pub fn rt_last_launch_config(s: *mut rt_scene, out: *mut rt_launch_config) -> c_int;
 

@@ -308,6 +308,27 @@ impl BoundingVolumeHierarchyNode {
         Ok(Self { raw })
     }
 
+    /// Wait for the renders launched on this world and report a device error word (a kernel that refused to run or made
+    /// no progress) as `Err` instead of a silent wrong image (`rt_render_status`).
+    pub fn status(&self) -> Result<(), Error> {
+        check(unsafe { ffi::rt_render_status(self.raw) })?;
+        Ok(())
+    }
+
+    /// Limit (bytes, 0 = default) and release of the per-sample workspace a render keeps on the device
+    /// (`rt_scene_set_workspace_limit`, `rt_scene_trim`); larger renders run in several passes, bit-identically.
+    pub fn set_workspace_limit(&self, bytes: usize) -> Result<(), Error> {
+        check(unsafe { ffi::rt_scene_set_workspace_limit(self.raw, bytes) })?;
+        Ok(())
+    }
+    pub fn trim(&self) -> Result<(), Error> {
+        check(unsafe { ffi::rt_scene_trim(self.raw) })?;
+        Ok(())
+    }
+    pub fn workspace_bytes(&self) -> usize {
+        unsafe { ffi::rt_scene_workspace_bytes(self.raw) }
+    }
+
     /// The thread fan-out + mpsc gather of examples/book-one.rs:52-88 across GPUs: `worlds[i]` is a committed copy on
     /// its own device, tiles are dealt `tile_id % worlds.len()`, one host thread per copy inside the library.
     /// Bit-identical to `render` for any number of copies.

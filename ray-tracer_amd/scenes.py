@@ -361,3 +361,62 @@ def instanced(aspect: float = 1.0, seed: int = 1) -> SceneDesc:
     d.world = [c1, c2, c3, p1, p2, m1, m2, m3, m4, floor, lamp, sky]
     d.camera = ((0.0, 4.0, -11.0), (0.0, 2.0, 2.0), (0.0, 1.0, 0.0), radians(45.0), float(aspect), 10.0, 0.0)
     return d
+
+
+def deep_chains(aspect: float = 1.0, seed: int = 1) -> SceneDesc:
+    """Not one of the reference's examples: transform nesting beyond the four levels every kernel family unrolls (src/sprite.rs:87-93
+    and src/geometry.rs:185-246 nest without bound; the product walks up to 15).  A sphere behind six TransformedGeometry levels, a
+    cube at the bottom of four nested nodes (six levels above its faces), a rectangle under non-rigid matrices, a ConstantMedium
+    five levels down, and one whose BOUNDARY is a cube behind five levels -- pure translations mixed in at every depth."""
+    d = SceneDesc(name="deep-chains")
+    g = HostRng(seed)
+    ex, ey, ez = (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)
+
+    def tr(t, rad=0.0, axis=ey):
+        return mat4_multiplied(mat4_translation(t), mat4_rotation(rad, axis))
+
+    def small(k):  # a small rigid or non-rigid step; every third one a pure translation
+        t = (g.gen_range(-0.3, 0.3), g.gen_range(-0.2, 0.2), g.gen_range(-0.3, 0.3))
+        if k % 3 == 2:
+            return mat4_translation(t)
+        m = tr(t, g.gen_range(-0.6, 0.6), (ex, ey, ez)[k % 3])
+        if k % 4 == 1:  # non-rigid on purpose (quirk Q5)
+            m = mat4_multiplied(m, [1.2, 0.0, 0.0, 0.0, 0.0, 0.85, 0.0, 0.0, 0.0, 0.0, 1.1, 0.0, 0.0, 0.0, 0.0, 1.0])
+        return m
+
+    white = d.lambertian_rgb((0.73, 0.73, 0.73))
+    red = d.lambertian_rgb((0.65, 0.05, 0.05))
+    glass = d.mat("dielectric", 1.5)
+    steel = d.mat("metal", d.tex_solid((0.8, 0.8, 0.9)), 0.1)
+    smoke = d.mat("isotropic", d.tex_solid((0.9, 0.9, 0.9)))
+    dark = d.mat("isotropic", d.tex_solid((0.1, 0.1, 0.1)))
+    # a sphere behind six TransformedGeometry levels (+ the sprite: 7)
+    geo = d.geom("sphere", 0.7)
+    for k in range(6):
+        geo = d.geom("transformed", geo, small(k))
+    s1 = d.sprite(geo, glass, tr((-2.5, 1.2, 0.5), 0.3, ey))
+    # a cube at the bottom of four nested nodes (sprite, 4 x (node sprite), face: 6 levels above each rectangle)
+    node = d.geom("bvh", [d.sprite(d.geom("cube", 0.9, 1.1, 0.8), None, small(1))])
+    for k in range(3):
+        node = d.geom("bvh", [d.sprite(node, None, small(k + 2))])
+    s2 = d.sprite(node, steel, tr((0.2, 1.0, 0.8), -0.4, ey))
+    # a rectangle under five levels, two of them non-rigid
+    geo = d.geom("rectangle", 1.6, 1.0)
+    for k in range(4):
+        geo = d.geom("transformed", geo, small(k + 1))
+    s3 = d.sprite(geo, red, tr((2.4, 1.3, 0.6), 0.5, ex))
+    # a ConstantMedium five levels down (sphere boundary), and one whose boundary is a cube behind five levels
+    geo = d.geom("medium", d.geom("sphere", 0.8), 1.4)
+    for k in range(4):
+        geo = d.geom("transformed", geo, small(k))
+    s4 = d.sprite(geo, smoke, tr((-1.0, 2.8, 1.5), 0.2, ez))
+    geo = d.geom("cube", 1.0, 1.4, 1.0)
+    for k in range(5):
+        geo = d.geom("transformed", geo, small(k + 2))
+    s5 = d.sprite(d.geom("medium", geo, 1.1), dark, tr((1.6, 2.9, 1.2), -0.3, ey))
+    floor = d.sprite(d.geom("rectangle", 30.0, 30.0), white, tr((0.0, 0.0, 0.0), radians(-90.0), ex))
+    lamp = d.sprite(d.geom("rectangle", 5.0, 5.0), d.mat("diffuse_light", d.tex_solid((5.0, 5.0, 5.0))), tr((0.0, 7.0, 1.0), radians(90.0), ex))
+    sky = d.sprite(d.geom("sphere", 60.0), d.mat("diffuse_light", d.tex_solid((0.3, 0.35, 0.45))), None)
+    d.world = [s1, s2, s3, s4, s5, floor, lamp, sky]
+    d.camera = ((0.0, 3.0, -9.0), (0.0, 1.6, 1.0), (0.0, 1.0, 0.0), radians(42.0), float(aspect), 10.0, 0.0)
+    return d

@@ -5,6 +5,7 @@
 // without a GPU.  It is not part of librt_mi355x.so and nothing in the product
 // calls it; GPU parity is established separately by the `-m gpu` tests.
 #include "../ray-tracer_amd/csrc/rt_lane.h"
+#include "../ray-tracer_amd/csrc/rt_lds.h"
 #include "../ray-tracer_amd/csrc/rt_scene_priv.h"
 #include "../include/rt_mi355x.h"
 
@@ -186,4 +187,22 @@ extern "C" void lane_emul_medium_forms(const double oc[3], const double d[3], do
     out[1] = ha ? a.t : 0.0;
     out[2] = hb ? 1.0 : 0.0;
     out[3] = hb ? b.t : 0.0;
+}
+
+// the shared LDS layout (ray-tracer_amd/csrc/rt_lds.h) for host-side sweeps: out = {stack_off, node_off, job_off, swap_off,
+// swap_class_bytes, total, aligned, cap that fits, effective cap}
+extern "C" void lane_emul_lds_layout(unsigned stack_entries, unsigned block, unsigned entry_bytes, unsigned node_bytes, unsigned groups_per_cu,
+                                     unsigned *out) {
+    const uint32_t cap = rt_swap_cap_that_fits(stack_entries, block, entry_bytes, node_bytes, groups_per_cu);
+    const uint32_t eff = rt_swap_cap_effective(block, cap);
+    const RtLdsLayout l = rt_lds_layout(stack_entries, block, entry_bytes, node_bytes, eff);
+    out[0] = l.stack_off;
+    out[1] = l.node_off;
+    out[2] = l.job_off;
+    out[3] = l.swap_off;
+    out[4] = l.swap_class_bytes;
+    out[5] = l.total;
+    out[6] = rt_lds_layout_aligned(l) ? 1u : 0u;
+    out[7] = cap;
+    out[8] = eff;
 }

@@ -51,3 +51,15 @@ def medium_forms(oc, d, radius, density, base=12345, segment=0, slot=0):
     oc, d, out = np.ascontiguousarray(oc, dtype=np.float64), np.ascontiguousarray(d, dtype=np.float64), np.zeros(4)
     _LIB.lane_emul_medium_forms(oc.ctypes.data_as(_DP), d.ctypes.data_as(_DP), radius, density, base, segment, slot, out.ctypes.data_as(_DP))
     return (bool(out[0]), float(out[1])), (bool(out[2]), float(out[3]))
+
+
+_LIB.lane_emul_lds_layout.restype = None
+_LIB.lane_emul_lds_layout.argtypes = [C.c_uint] * 5 + [C.POINTER(C.c_uint)]
+
+
+def lds_layout(stack_entries, block, entry_bytes, node_bytes, groups_per_cu):
+    """rt_lds.h for a launch shape -> dict of offsets, total, aligned, the queue capacity that fits and the one the kernel uses"""
+    out = (C.c_uint * 9)()
+    _LIB.lane_emul_lds_layout(stack_entries, block, entry_bytes, node_bytes, groups_per_cu, out)
+    names = ("stack_off", "node_off", "job_off", "swap_off", "swap_class_bytes", "total", "aligned", "cap", "cap_effective")
+    return dict(zip(names, [int(v) for v in out]))

@@ -1,7 +1,9 @@
 """world_size-2 (and 3) gloo test of the multi-rank path of bench.py: every rank owns the
 tiles with tile_id % N == rank, packs them as the kernels do, ONE gather brings equal-sized
-shards to rank 0, which un-permutes them.  The renderer stand-in on CPU is the host compile
-of the lane program (tests only); the permutation logic is what is under test here."""
+shards to rank 0, which un-permutes them.  The pixel values on CPU come from the host compile
+of the lane program (tests only); the permutations under test are the PRODUCT's own
+(librt_mi355x: rt_shard_tile_count, rt_pack_tiles_host, rt_unpack_tiles_host -- the loops rt_render and
+rt_render_progressive run on every call), checked against the numpy restatement of the kernels' layout as well."""
 import os
 import sys
 from pathlib import Path
@@ -33,12 +35,15 @@ def _worker(rank, world, port, W, H, q):
     pad = max(counts)
     assert counts[rank] == len(sm.owned_tiles(W, H, rank, world))
     full, *_ = le.render(sc, cam, W, H, 2, 20, 5)  # sample streams are global: any rank computes the same pixels
-    mine = torch.from_numpy(sm.pack_tiles(full, rank, world, pad).reshape(-1))
+    packed = rt.pack_tiles_host(full, rank, world, pad)            # the product's permutation ...
+    assert np.array_equal(packed, sm.pack_tiles(full, rank, world, pad))  # ... is the kernels' layout
+    mine = torch.from_numpy(packed.reshape(-1))
     glist = [torch.zeros_like(mine) for _ in range(world)] if rank == 0 else None
     dist.gather(mine, glist, dst=0)
     if rank == 0:
-        img = sm.unpack_tiles(torch.cat(glist).numpy(), pad, world, W, H)
-        q.put(bool(np.array_equal(img, full)))
+        gathered = torch.cat(glist).numpy()
+        img = rt.unpack_tiles_host(gathered, pad, world, W, H)
+        q.put(bool(np.array_equal(img, full)) and bool(np.array_equal(img, sm.unpack_tiles(gathered, pad, world, W, H))))
     dist.barrier()
     dist.destroy_process_group()
 

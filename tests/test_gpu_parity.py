@@ -275,6 +275,69 @@ def test_config5_one_full_shard_3840x2160x2000(rt, scenes, oracle, gpu_device):
         checked += 1
 
 
+def test_config0_book_one_400x225x50_depth_50_whole_image(rt, scenes, oracle, gpu_device):
+    """configs[0]: the reference's own CPU-runnable case -- 400x225, 50 spp, 50 bounces -- EVERY pixel against the oracle
+    (4.5 M samples: seconds on the GPU box's host cores)."""
+    import os
+    W, H, spp, depth = 400, 225, 50, 50
+    desc = scenes.book_one(1, W / H)
+    sc, cam = scenes.build_product(desc, device=gpu_device)
+    img = sc.render(cam, W, H, spp, depth, seed=1)
+    ref = oracle.build_oracle(desc).render(W, H, spp, depth, seed=1, iterative=True, nthreads=min(64, os.cpu_count() or 8))
+    _close(img, ref, max_bad=0)
+    assert np.array_equal(img, ref)  # book-one has no libm call on the device: bit for bit
+    assert float(np.abs(img - ref).mean()) <= 1e-4  # the north star's stated bar
+
+
+def test_config5_all_eight_shards_3840x2160x2000(rt, scenes, oracle, gpu_device):
+    """configs[4] at its size: ALL eight shards of 3840x2160 at 2000 spp (16.6 G samples, 8 x ~0.28 s on one MI355X, each in
+    three passes over the workspace), rendered one after another as eight GPUs would render them side by side, recombined:
+    finite, in range, no pixel left out or written twice, 64 pixels spread over all shards equal to the oracle at 2000 spp;
+    and the library's own fan-out over 8 committed copies (rt_render_sharded: what the C++ / Rust drivers call with --gpus 8)
+    equals the one-call render at a reduced sample count.  What this box cannot run is the gather over 8 physical GPUs."""
+    W, H, spp, depth = 3840, 2160, 2000, 100
+    desc = scenes.book_one(1, W / H)
+    sc, cam = scenes.build_product(desc, device=gpu_device)
+    img = np.zeros((H, W, 3))
+    covered = np.zeros((H, W), dtype=np.int32)
+    tiles_x = (W + 7) // 8
+    yy, xx = np.mgrid[0:H, 0:W]
+    owner = ((yy // 8) * tiles_x + xx // 8) % 8
+    for r in range(8):
+        part = sc.render(cam, W, H, spp, depth, 1, shard=(r, 8))
+        assert np.all(part[owner != r] == 0.0)  # a shard writes its own tiles only
+        img += part
+        covered += (owner == r)
+    assert np.all(covered == 1)
+    assert sc.last_launch_config()["passes"] >= 2
+    assert np.isfinite(img).all() and img.min() >= 0.0 and img.max() <= 1.0 + 1e-12  # sky (0.5,0.7,1) times albedos <= 1
+    o = oracle.build_oracle(desc)
+    rng = np.random.default_rng(21)
+    per_shard = {r: 0 for r in range(8)}
+    while min(per_shard.values()) < 8:  # 64 pixels, 8 per shard
+        x, y = int(rng.integers(W)), int(rng.integers(H))
+        r = int(owner[y, x])
+        if per_shard[r] >= 8:
+            continue
+        ref = o.render(W, H, spp, depth, 1, region=(x, y, x + 1, y + 1), iterative=True)[y, x]
+        assert np.array_equal(img[y, x], ref), (x, y, r, img[y, x], ref)
+        per_shard[r] += 1
+    sc.trim()
+    # the in-library fan-out over eight copies == one render, at 3 spp
+    copies = [sc] + [sc.clone(gpu_device) for _ in range(7)]
+    assert np.array_equal(rt.render_sharded(copies, cam, W, H, 3, depth, seed=1), sc.render(cam, W, H, 3, depth, seed=1))
+
+
+def test_deep_transform_chains_match_oracle(rt, scenes, oracle, gpu_device):
+    """more than four transform levels above a primitive (RT_FEAT_DEEP_CHAIN): the general-media kernel family walks up to 15"""
+    d = scenes.deep_chains(1.25, seed=1)
+    sc, cam = scenes.build_product(d, device=gpu_device)
+    assert sc.info()["feature_mask"] & rt.RT_FEAT_DEEP_CHAIN
+    img = sc.render(cam, 100, 80, 16, 40, seed=3)
+    assert sc.last_launch_config()["kernel_features"] & 8
+    _close(img, oracle.build_oracle(d).render(100, 80, 16, 40, seed=3, iterative=True, nthreads=8), max_bad=4)
+
+
 def test_render_sharded_over_scene_clones(rt, scenes, gpu_device):
     """rt_scene_clone + rt_render_sharded: the drivers' thread fan-out (examples/book-one.rs:52-88) inside the library --
     one host thread per committed copy, tiles dealt tile_id % n; clones wrap around on this one-GPU box"""

@@ -247,12 +247,19 @@ def rt_feat(scenes, name):
 
 
 def test_chain_depth_limit_is_reported(rt, scenes):
-    """five transform levels above a sphere: outside RT_MAX_CHAIN, an error at commit, never a wrong picture"""
-    s = rt.Scene()
-    node = s.bvh([s.sprite(s.sphere(1.0), None, scenes.mat4_rotation(0.1, (0.0, 1.0, 0.0)))])
-    for _ in range(3):
-        node = s.bvh([s.sprite(node, None, scenes.mat4_rotation(0.1, (0.0, 1.0, 0.0)))])
-    s.sprite(node, None, scenes.mat4_rotation(0.1, (0.0, 1.0, 0.0)))
+    """five transform levels above a sphere commit (round 2: an error; now the deep-chain family); sixteen are outside
+    RT_MAX_CHAIN_DEEP: an error at commit, never a wrong picture"""
+    def nested(levels):
+        s = rt.Scene()
+        node = s.bvh([s.sprite(s.sphere(1.0), None, scenes.mat4_rotation(0.1, (0.0, 1.0, 0.0)))])
+        for _ in range(levels - 2):
+            node = s.bvh([s.sprite(node, None, scenes.mat4_rotation(0.1, (0.0, 1.0, 0.0)))])
+        s.sprite(node, None, scenes.mat4_rotation(0.1, (0.0, 1.0, 0.0)))
+        return s
+    s = nested(5)
+    s.commit(-1)
+    assert s.info()["feature_mask"] & rt.FEAT_DEEP_CHAIN
+    s = nested(16)
     with pytest.raises(rt.RtError) as e:
         s.commit(-1)
     assert e.value.code == -4 and "transform levels" in str(e.value)
@@ -279,3 +286,29 @@ def test_scene_above_the_16_bit_reference_limit_exact(scenes, oracle, lane_emul)
     img, cnt, high = lane_emul.render(sc, cam, 30, 20, 2, 30, 3)
     assert np.array_equal(img, oracle.build_oracle(d).render(30, 20, 2, 30, 3, iterative=True, nthreads=8))
     assert high <= info["max_depth"] + 1 <= 24
+
+
+def test_deep_transform_chains_exact(scenes, oracle, lane_emul, rt):
+    """More than four transform levels above a primitive (src/sprite.rs:87-93 nests without bound; round 2 returned
+    RT_ERR_UNSUPPORTED): up to 15 are walked by the kernel family for general media, the levels beyond the fourth in the
+    reference's own full 4x4 form.  Spheres, cube faces, a rectangle, a medium and a medium's boundary at depths 5-7."""
+    d = scenes.deep_chains(1.25, seed=1)
+    img, ref, cnt, ocnt, high, sc = both(scenes, oracle, lane_emul, d, 60, 48, 6, 40)
+    assert sc.info()["feature_mask"] & rt.FEAT_DEEP_CHAIN
+    assert np.array_equal(img, ref)
+    assert cnt["segments"] == ocnt["segments"]
+    assert img.std() > 0.05  # the objects are in the picture
+    img2, ref2, *_ = both(scenes, oracle, lane_emul, scenes.deep_chains(1.0, seed=5), 40, 40, 4, 40, seed=9)
+    assert np.array_equal(img2, ref2)
+
+
+def test_sixteen_levels_are_still_an_error(scenes, rt):
+    d = scenes.SceneDesc()
+    geo = d.geom("sphere", 1.0)
+    for _ in range(15):
+        geo = d.geom("transformed", geo, scenes.mat4_translation((0.1, 0.0, 0.0)))
+    d.sprite(geo, d.lambertian_rgb((0.5, 0.5, 0.5)), None)  # 15 + the sprite's own level = 16
+    d.camera = ((0.0, 0.0, -5.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 0.8, 1.0, 10.0, 0.0)
+    with pytest.raises(rt.RtError) as e:
+        scenes.build_product(d, device=-1)
+    assert e.value.code == rt.ERR_UNSUPPORTED and "15" in str(e.value)
