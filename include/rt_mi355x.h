@@ -165,6 +165,12 @@ typedef struct rt_counters {
      * ones scattered outside the chosen class (could not be parked) */
     uint64_t swap_class_mode, swap_new_mode, swap_parked, swap_pulled, swap_lock_busy, swap_scattered, swap_off_class;
     uint64_t swap_cycles; /* of finish_cycles: classification + queue traffic of the swap (counting build) */
+    /* lanes that sat idle while the node block ran, by what they were waiting for: a finished segment waiting for the shade
+     * quorum, a leaf waiting for the leaf quorum, no path at all */
+    uint64_t node_idle_done, node_idle_leaf, node_idle_empty;
+    /* ray exchange (kernels with the ray queue): executions of the exchange block, hits parked and rays pulled by it, rays
+     * a shading wave pushed for others */
+    uint64_t xchg_wave, xchg_parked, xchg_pulled, xchg_pushed;
 } rt_counters;
 
 /* Render into host memory: out_rgb[(y*W + x)*3 + c].  With shard_count > 1 only

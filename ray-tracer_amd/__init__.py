@@ -52,7 +52,9 @@ class rt_counters(C.Structure):
                                             "node_wave", "node_lane", "leaf_wave", "leaf_lane", "shade_wave", "shade_lane",
                                             "node_cycles", "leaf_cycles", "shade_cycles", "finish_cycles", "refill_cycles",
                                             "begin_cycles", "swap_class_mode", "swap_new_mode", "swap_parked", "swap_pulled",
-                                            "swap_lock_busy", "swap_scattered", "swap_off_class", "swap_cycles")]
+                                            "swap_lock_busy", "swap_scattered", "swap_off_class", "swap_cycles",
+                                            "node_idle_done", "node_idle_leaf", "node_idle_empty",
+                                            "xchg_wave", "xchg_parked", "xchg_pulled", "xchg_pushed")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -348,13 +348,16 @@ static unsigned kernel_features(const rt_scene *s) {
 // (an MI355X has 288 GB: 32 GiB; the headline 1200x800x500 render needs 15.36 GB and runs in one pass).  The workspace is
 // allocated at the size a render needs (never the cap), grows on demand, is reused by later renders and is given back by
 // rt_scene_trim / rt_scene_destroy.
-static size_t sample_workspace_cap(const rt_scene *s) {
+static size_t sample_workspace_cap(rt_scene *s) {
     if (s->workspace_limit) return s->workspace_limit;
     const char *e = std::getenv("RT_SAMPLE_WORKSPACE_MB");
     if (e && *e) return (size_t)std::strtoull(e, nullptr, 10) << 20;
-    size_t cap = (size_t)32 << 30, free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b / 4 < cap) cap = total_b / 4;
-    return cap;
+    if (!s->workspace_default) { // asked once per scene: hipMemGetInfo is not free and may wait for the device
+        size_t cap = (size_t)32 << 30, free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b / 4 < cap) cap = total_b / 4;
+        s->workspace_default = cap;
+    }
+    return s->workspace_default;
 }
 
 // the device error word of a slot (rt_lds.h RT_DEV_*): read, cleared, turned into RT_ERR_DEVICE.  The slot's work has finished.
@@ -722,6 +725,13 @@ int rt_render(rt_scene *s, const rt_camera *cam, const rt_render_params *p, doub
             counters->swap_scattered = c.swap_scattered;
             counters->swap_off_class = c.swap_off_class;
             counters->swap_cycles = c.swap_cycles;
+            counters->node_idle_done = c.node_idle_done;
+            counters->node_idle_leaf = c.node_idle_leaf;
+            counters->node_idle_empty = c.node_idle_empty;
+            counters->xchg_wave = c.xchg_wave;
+            counters->xchg_parked = c.xchg_parked;
+            counters->xchg_pulled = c.xchg_pulled;
+            counters->xchg_pushed = c.xchg_pushed;
         }
     }
     (void)hipFree(d_out);

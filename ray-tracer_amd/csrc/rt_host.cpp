@@ -850,6 +850,12 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
         const uint32_t mk = m.material == RT_NO_MATERIAL ? (uint32_t)RT_MAT_KIND_NONE : fs.materials[m.material].kind;
         m.kind = (m.kind & ~0xFF00u) | (mk << 8);
     }
+    // the kernels address every scene array with a 32-bit byte offset built from a 24-bit record index (rtl::rec_at)
+    const size_t most = std::max({fs.prim_meta.size(), fs.xforms.size(), fs.materials.size(), fs.textures.size(), fs.nodes.size()});
+    if (most > (size_t)RT_MAX_RECORDS || fs.image_blob.size() >= ((size_t)1 << 32)) {
+        if (err) *err = "more than 2^24 records in one scene array (prims, transforms, materials, textures, nodes) or 4 GiB of texels";
+        return RT_ERR_UNSUPPORTED;
+    }
     *out = std::move(fs);
     return RT_OK;
 }

@@ -122,7 +122,10 @@
 #define RT_SWAP_MODE_MIN 56 /* a class needs this many lanes (own + parked) to be chosen over starting new samples */
 #endif
 #ifndef RT_SWAP_REFILL_MIN
-#define RT_SWAP_REFILL_MIN 65 /* empty lanes that force a refill even in a class mode */
+#define RT_SWAP_REFILL_MIN 65 /* empty lanes that force a refill even in a class mode (spheres-only family: never) */
+#endif
+#ifndef RT_SWAP_REFILL_MIN_G
+#define RT_SWAP_REFILL_MIN_G 65 /* the same for the general families */
 #endif
 #ifndef RT_SWAP_EARLY_RELEASE
 #define RT_SWAP_EARLY_RELEASE 1
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
     bool queue_empty = false;
 
     unsigned long long c_nodes = 0, c_prims = 0, c_segs = 0, c_draws = 0, c_samples = 0;
-    unsigned long long c_nw = 0, c_nl = 0, c_lw = 0, c_ll = 0, c_sw = 0, c_sl = 0;
+    unsigned long long c_nw = 0, c_nl = 0, c_lw = 0, c_ll = 0, c_sw = 0, c_sl = 0, c_id = 0, c_il = 0, c_ie = 0;
     unsigned long long t_n = 0, t_l = 0, t_s = 0, t_fin = 0, t_ref = 0, t_beg = 0, t0 = 0, t1 = 0;
     unsigned long long w_class = 0, w_new = 0, w_park = 0, w_pull = 0, w_busy = 0, w_scat = 0, w_off = 0, t_swap = 0; // swap diagnostics
 #define RT_STAMP(v) do { if (COUNT) v = __builtin_amdgcn_s_memtime(); } while (0)
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                 if (is_done && has_path) {
                     uint32_t mat = RT_NO_MATERIAL, kind = RT_MAT_KIND_NONE;
                     if (tv.best_prim != 0xFFFFFFFFu) { // one 8-byte load: the material's kind rides in the meta word
-                        const uint2 pm = *reinterpret_cast<const uint2 *>(&L.prim_meta[tv.best_prim]);
+                        const uint2 pm = *reinterpret_cast<const uint2 *>((GENERAL || MEDIUM) ? &rtl::rec_at(L.prim_meta, tv.best_prim) : &L.prim_meta[tv.best_prim]);
                         kind = (pm.x >> 8) & 0xFFu;
                         mat = pm.y;
                     }
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                         cls = kInPlace;
                     } else {
                         rtl::V3 rad = rtl::mk(0.0, 0.0, 0.0);
-                        if (kind == RT_MAT_DIFFUSE_LIGHT) rad = ps.T * rtl::ld3(L.materials[mat].rgb); // finish_segment's T * emit
+                        if (kind == RT_MAT_DIFFUSE_LIGHT) rad = ps.T * rtl::ld3(((GENERAL || MEDIUM) ? rtl::rec_at(L.materials, mat) : L.materials[mat]).rgb); // finish_segment's T * emit
                         store_sample(L.samples, slot, rad);
                         has_path = false;
                         cls = kEmpty;
@@ -560,7 +563,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                 }
                 part = cls != kNone;
                 need = part && !has_path;
-                do_refill = mode_new || __popcll(__ballot(need)) >= RT_SWAP_REFILL_MIN;
+                do_refill = mode_new || __popcll(__ballot(need)) >= (GENERAL ? RT_SWAP_REFILL_MIN_G : RT_SWAP_REFILL_MIN);
             } else if (is_done) {
                 if (has_path) {
                     rtl::V3 rad;
@@ -690,9 +693,15 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
             if constexpr (LIST) {
                 // one step: all the leaves' boxes, every lane in lock step; the lanes leave as LEAF or DONE
                 const bool at_node = tv.cur < Ref::kLeaf;
-                if (COUNT && counting_lane) {
-                    ++c_nw;
-                    c_nl += (unsigned long long)nN;
+                if (COUNT) {
+                    const int n_done = __popcll(__ballot(tv.cur == Ref::kDone && has_path));
+                    if (counting_lane) {
+                        ++c_nw;
+                        c_nl += (unsigned long long)nN;
+                        c_il += (unsigned long long)nL;
+                        c_id += (unsigned long long)n_done;
+                        c_ie += (unsigned long long)(64 - nN - nL - n_done);
+                    }
                 }
                 if (at_node) {
                     if (COUNT) c_nodes += (unsigned long long)L.n_list;
@@ -703,13 +712,20 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                 const bool at_node = tv.cur < Ref::kLeaf;
                 const int n = __popcll(__ballot(at_node));
                 if (n == 0) break;
-                if (COUNT && counting_lane) {
-                    ++c_nw;
-                    c_nl += (unsigned long long)n;
+                if (COUNT) {
+                    const int n_leaf = __popcll(__ballot(tv.cur >= Ref::kLeaf && tv.cur < Ref::kDone));
+                    const int n_done = __popcll(__ballot(tv.cur == Ref::kDone && has_path));
+                    if (counting_lane) {
+                        ++c_nw;
+                        c_nl += (unsigned long long)n;
+                        c_il += (unsigned long long)n_leaf;
+                        c_id += (unsigned long long)n_done;
+                        c_ie += (unsigned long long)(64 - n - n_leaf - n_done);
+                    }
                 }
                 if (at_node) {
                     if (COUNT) ++c_nodes;
-                    rtl::trav_node_step(nodes, tv, st);
+                    rtl::trav_node_step<!LDSNODES>(nodes, tv, st);
                 }
                 if (n < kNodeKeep) break;
             }
@@ -741,6 +757,9 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
             atomicAdd(&L.counters->leaf_lane, c_ll);
             atomicAdd(&L.counters->shade_wave, c_sw);
             atomicAdd(&L.counters->shade_lane, c_sl);
+            atomicAdd(&L.counters->node_idle_done, c_id);
+            atomicAdd(&L.counters->node_idle_leaf, c_il);
+            atomicAdd(&L.counters->node_idle_empty, c_ie);
             atomicAdd(&L.counters->node_cycles, t_n);
             atomicAdd(&L.counters->leaf_cycles, t_l);
             atomicAdd(&L.counters->shade_cycles, t_fin + t_ref + t_beg);

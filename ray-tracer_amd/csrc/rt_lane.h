@@ -90,6 +90,24 @@ RT_HD V3 xf_vector(const double *m, V3 v) {
               m[8] * v.x + m[9] * v.y + m[10] * v.z + m[11] * 0.0);
 }
 
+// Record i of a scene array as base + a 32-BIT byte offset: the scene arrays are kernel arguments (uniform, in SGPRs), so the
+// load becomes `global_load ..., v_offset, s[base:base+1]` -- one full-rate 24-bit multiply (or shift) per record instead of the
+// 64-bit index arithmetic of base[i] (v_mad_u64_u32 / v_lshl_add_u64 pairs: quarter-rate, and a VGPR pair per address).  The
+// host limits every array to 2^24 records and 4 GiB (rt_host.cpp, RT_MAX_RECORDS).
+#if defined(__HIP_DEVICE_COMPILE__)
+RT_HD uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
+#else
+RT_HD uint32_t mul24(uint32_t a, uint32_t b) { return a * b; }
+#endif
+template <class T>
+RT_HD uint32_t rec_off(uint32_t i) { // byte offset of record i: a shift for the power-of-two records, one v_mul_u32_u24 for the others
+    return (sizeof(T) & (sizeof(T) - 1)) == 0 ? i * (uint32_t)sizeof(T) : mul24(i, (uint32_t)sizeof(T));
+}
+template <class T>
+RT_HD const T &rec_at(const T *base, uint32_t i) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const unsigned char *>(base) + rec_off<T>(i));
+}
+
 struct Rec { // HitRecord, src/ray.rs:36-43 (material lives on the prim)
     double t;
     V3 p, n;
@@ -418,7 +436,7 @@ RT_HD void chain_down(const RtLaunch &L, uint32_t first, uint32_t len, uint32_t 
 #endif
     for (uint32_t i = 0; i < (uint32_t)RT_MAX_CHAIN; ++i) {
         if (i >= len) continue;
-        const RtXform &X = L.xforms[first + i];
+        const RtXform &X = rec_at(L.xforms, first + i);
         if ((tmask >> i) & 1u) {
             *o = mk(o->x + X.inv[3], o->y + X.inv[7], o->z + X.inv[11]);
         } else {
@@ -431,7 +449,7 @@ RT_HD void chain_down(const RtLaunch &L, uint32_t first, uint32_t len, uint32_t 
     // always the full 4x4 products, the reference's own form (src/sprite.rs:101-106)
     if (DEEP)
         for (uint32_t i = (uint32_t)RT_MAX_CHAIN; i < len; ++i) {
-            const RtXform &X = L.xforms[first + i];
+            const RtXform &X = rec_at(L.xforms, first + i);
             const V3 lo = xf_point(X.inv, *o);
             *d = xf_vector(X.inv, *d);
             *o = lo;
@@ -440,14 +458,14 @@ RT_HD void chain_down(const RtLaunch &L, uint32_t first, uint32_t len, uint32_t 
 template <bool DEEP = false>
 RT_HD void chain_up(const RtLaunch &L, uint32_t first, uint32_t len, uint32_t tmask, Rec *r) {
     if (DEEP)
-        for (uint32_t i = len; i > (uint32_t)RT_MAX_CHAIN; --i) to_world(L.xforms[first + i - 1u], r);
+        for (uint32_t i = len; i > (uint32_t)RT_MAX_CHAIN; --i) to_world(rec_at(L.xforms, first + i - 1u), r);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (uint32_t k = 0; k < (uint32_t)RT_MAX_CHAIN; ++k) {
         const uint32_t i = (uint32_t)RT_MAX_CHAIN - 1u - k;
         if (i >= len) continue;
-        const RtXform &X = L.xforms[first + i];
+        const RtXform &X = rec_at(L.xforms, first + i);
         if ((tmask >> i) & 1u)
             r->p = mk(r->p.x + X.m[3], r->p.y + X.m[7], r->p.z + X.m[11]);
         else
@@ -458,14 +476,14 @@ RT_HD void chain_up(const RtLaunch &L, uint32_t first, uint32_t len, uint32_t tm
 template <bool DEEP = false>
 RT_HD void chain_up_point(const RtLaunch &L, uint32_t first, uint32_t len, uint32_t tmask, V3 *p) {
     if (DEEP)
-        for (uint32_t i = len; i > (uint32_t)RT_MAX_CHAIN; --i) *p = xf_point(L.xforms[first + i - 1u].m, *p);
+        for (uint32_t i = len; i > (uint32_t)RT_MAX_CHAIN; --i) *p = xf_point(rec_at(L.xforms, first + i - 1u).m, *p);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (uint32_t k = 0; k < (uint32_t)RT_MAX_CHAIN; ++k) {
         const uint32_t i = (uint32_t)RT_MAX_CHAIN - 1u - k;
         if (i >= len) continue;
-        const RtXform &X = L.xforms[first + i];
+        const RtXform &X = rec_at(L.xforms, first + i);
         if ((tmask >> i) & 1u)
             *p = mk(p->x + X.m[3], p->y + X.m[7], p->z + X.m[11]);
         else
@@ -501,13 +519,13 @@ RT_HD bool medium_general_hit(const RtLaunch &L, const RtPrimGeo &G, V3 o, V3 d,
         bool have = false;
         for (uint32_t k = 0; k < count; ++k) {
             const uint32_t ci = first + k;
-            const uint32_t kw = L.prim_meta[ci].kind;
-            const uint32_t cf = L.prim_meta[ci].xform, cl = (kw >> RT_META_CHAIN_SHIFT) & 0xFu, cm = (kw >> RT_META_TMASK_SHIFT) & 0xFu;
+            const uint32_t kw = rec_at(L.prim_meta, ci).kind;
+            const uint32_t cf = rec_at(L.prim_meta, ci).xform, cl = (kw >> RT_META_CHAIN_SHIFT) & 0xFu, cm = (kw >> RT_META_TMASK_SHIFT) & 0xFu;
             V3 co = ro, cd = d;
             chain_down<true>(L, cf, cl, cm, &co, &cd);
             Rec cr;
             ++*tests;
-            if (shape_hit<true>(kw & 0xFFu, L.prim_geo[ci], co, cd, uv, &cr) && (!have || cr.t < best.t)) {
+            if (shape_hit<true>(kw & 0xFFu, rec_at(L.prim_geo, ci), co, cd, uv, &cr) && (!have || cr.t < best.t)) {
                 chain_up<true>(L, cf, cl, cm, &cr);
                 best = cr;
                 have = true;
@@ -554,9 +572,10 @@ template <bool GENERAL, int MEDIUM, bool RECORD>
 RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx &sc, Rec *r, bool uv_wanted) {
     // uv inside the record is only ever asked for by prim_uv's medium case (kernel family MEDIUM = 2)
     const bool uv = MEDIUM >= 2 && uv_wanted;
-    const RtPrimGeo &G = L.prim_geo[pi];
+    // (the spheres-only family keeps the plain indexing: measured 0.9 % faster there, 2.5 % slower on the book-two cover)
+    const RtPrimGeo &G = (GENERAL || MEDIUM) ? rec_at(L.prim_geo, pi) : L.prim_geo[pi];
     uint32_t kw = (uint32_t)RT_PRIM_SPHERE_T;
-    if (GENERAL || MEDIUM) kw = L.prim_meta[pi].kind; // bits 8-15 carry the material's kind, 16-23 the chain
+    if (GENERAL || MEDIUM) kw = rec_at(L.prim_meta, pi).kind; // bits 8-15 carry the material's kind, 16-23 the chain
     const uint32_t kind = kw & 0xFFu;
     ++sc.prims_tested;
     if (kind == RT_PRIM_SPHERE_T) {
@@ -574,10 +593,10 @@ RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx
         return true;
     }
     if (GENERAL || MEDIUM) {
-        const RtPrimMeta &P = L.prim_meta[pi];
+        const RtPrimMeta &P = rec_at(L.prim_meta, pi);
         if (MEDIUM && kind == RT_PRIM_MEDIUM_T) {
             V3 c = mk(G.g[0], G.g[1], G.g[2]);
-            if (!medium_hit<RECORD>(o - c, d, G.g[3], L.prim_extra[pi].e[1], sc.rng_base, sc.segment, P.aux, &sc.draws, uv, r)) return false;
+            if (!medium_hit<RECORD>(o - c, d, G.g[3], rec_at(L.prim_extra, pi).e[1], sc.rng_base, sc.segment, P.aux, &sc.draws, uv, r)) return false;
             if (RECORD) r->p = r->p + c;
             return true;
         }
@@ -603,9 +622,9 @@ RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx
 // in geo.g[2], geo.g[3], extra.e[0].  Media go through the full test (keyed draw, both boundary hits).
 template <bool GENERAL, int MEDIUM>
 RT_HD void prim_record(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double t, SegCtx &sc, Rec *r) {
-    const RtPrimGeo &G = L.prim_geo[pi];
+    const RtPrimGeo &G = rec_at(L.prim_geo, pi);
     uint32_t kw = (uint32_t)RT_PRIM_SPHERE_T;
-    if (GENERAL || MEDIUM) kw = L.prim_meta[pi].kind;
+    if (GENERAL || MEDIUM) kw = rec_at(L.prim_meta, pi).kind;
     const uint32_t kind = kw & 0xFFu;
     if (kind == RT_PRIM_SPHERE_T) {
         const V3 c = mk(G.g[0], G.g[1], G.g[2]);
@@ -618,7 +637,7 @@ RT_HD void prim_record(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double t, Seg
             prim_hit<GENERAL, MEDIUM, true>(L, pi, o, d, dot(d, d), sc, r, false);
             return;
         }
-        const uint32_t first = L.prim_meta[pi].xform, len = (kw >> RT_META_CHAIN_SHIFT) & 0xFu, tmask = (kw >> RT_META_TMASK_SHIFT) & 0xFu;
+        const uint32_t first = rec_at(L.prim_meta, pi).xform, len = (kw >> RT_META_CHAIN_SHIFT) & 0xFu, tmask = (kw >> RT_META_TMASK_SHIFT) & 0xFu;
         V3 lo = o, ld = d;
         chain_down<(MEDIUM >= 2)>(L, first, len, tmask, &lo, &ld);
         if (kind == RT_PRIM_SPHERE_C) {
@@ -630,7 +649,7 @@ RT_HD void prim_record(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double t, Seg
             r->v = 0.0;
             r->p = lo + ld * t;
             chain_up_point<(MEDIUM >= 2)>(L, first, len, tmask, &r->p);
-            r->n = mk(G.g[2], G.g[3], L.prim_extra[pi].e[0]);
+            r->n = mk(G.g[2], G.g[3], rec_at(L.prim_extra, pi).e[0]);
         }
     }
 }
@@ -756,19 +775,24 @@ RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack
 struct F2 {
     float a, b;
 };
-RT_HD F2 ld_pair(const RtNode *n, uint32_t byte_off) {
-    const float *p = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(n) + byte_off);
+RT_HD F2 ld_pair(const RtNode *base, uint32_t byte_off) { // base: a node (LDS copy) or the node ARRAY (global: one 32-bit offset per load)
+    const float *p = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(base) + byte_off);
     F2 r;
     r.a = p[0];
     r.b = p[1];
     return r;
 }
-template <class Stack>
+// GLOBAL: the node array is in global memory: every load is `array base (SGPRs) + one 32-bit offset` (seven v_add_u32 instead
+// of seven 64-bit v_lshl_add_u64 and six VGPR pairs of offsets: -2 % on the book-two cover); the LDS copy keeps node pointer +
+// plane offset (one v_lshl_add_u32 for the node, one v_add_u32 per plane)
+template <bool GLOBAL = false, class Stack>
 RT_HD void trav_node_step(const RtNode *nodes, Trav &tv, Stack &st) {
-    const RtNode *N = &nodes[tv.cur];
-    const F2 px = ld_pair(N, tv.ox), py = ld_pair(N, tv.oy), pz = ld_pair(N, tv.oz);                   // entry planes
-    const F2 qx = ld_pair(N, tv.ox ^ 24u), qy = ld_pair(N, tv.oy ^ 40u), qz = ld_pair(N, tv.oz ^ 56u); // exit planes
-    const uint32_t c0 = N->child[0], c1 = N->child[1];
+    const uint32_t nb = GLOBAL ? rec_off<RtNode>(tv.cur) : 0u;
+    const RtNode *N = GLOBAL ? nodes : &nodes[tv.cur];
+    const F2 px = ld_pair(N, nb + tv.ox), py = ld_pair(N, nb + tv.oy), pz = ld_pair(N, nb + tv.oz);                   // entry planes
+    const F2 qx = ld_pair(N, nb + (tv.ox ^ 24u)), qy = ld_pair(N, nb + (tv.oy ^ 40u)), qz = ld_pair(N, nb + (tv.oz ^ 56u)); // exit planes
+    const uint32_t *cp = reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(N) + (nb + 48u)); // RtNode::child
+    const uint32_t c0 = cp[0], c1 = cp[1];
     // fminf / fmaxf ignore a NaN operand (0 * inf planes), like the reference's selects: such an axis drops out
     const float tmin0 = fmaxf(fmaxf(fmaf(px.a, tv.idx, tv.nx), fmaf(py.a, tv.idy, tv.ny)), fmaxf(fmaf(pz.a, tv.idz, tv.nz), 0.0f));
     const float tmin1 = fmaxf(fmaxf(fmaf(px.b, tv.idx, tv.nx), fmaf(py.b, tv.idy, tv.ny)), fmaxf(fmaf(pz.b, tv.idz, tv.nz), 0.0f));
@@ -851,7 +875,7 @@ RT_HD uint32_t as_u32(double x) { // Rust `as u32`: saturating, NaN -> 0
 }
 RT_HD V3 texture_value(const RtLaunch &L, uint32_t tex, double u, double v) {
     for (int guard = 0; guard < 64; ++guard) {
-        const RtTexture &T = L.textures[tex];
+        const RtTexture &T = rec_at(L.textures, tex);
         if (T.kind == RT_TEX_SOLID) return ld3(T.rgb);
         if (T.kind == RT_TEX_CHECKER) {
             double sine = checker_sine_cold(u, v);
@@ -862,7 +886,7 @@ RT_HD V3 texture_value(const RtLaunch &L, uint32_t tex, double u, double v) {
         uint32_t py = as_u32((1.0 - v) * (double)T.h);
         if (px >= T.w) px = T.w - 1; // the reference would panic here (u == 1.0); clamp, see DESIGN.md
         if (py >= T.h) py = T.h - 1;
-        const uint8_t *t = L.image_blob + T.data + ((size_t)py * T.w + px) * 3;
+        const uint8_t *t = L.image_blob + (uint32_t)(T.data + (py * T.w + px) * 3u); // the blob is < 4 GiB (rt_host.cpp)
         return mk((double)t[0] / 255.0, (double)t[1] / 255.0, (double)t[2] / 255.0);
     }
     return mk(0.0, 0.0, 0.0);
@@ -973,11 +997,11 @@ RT_HD bool shade(const RtMaterial &M, V3 tex, const Rec &rec, V3 d_in, Rng &g, V
 // hits (src/volume.rs:64-66) and come out of the full medium test.
 template <bool GENERAL, int MEDIUM>
 RT_HD void prim_uv(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double t, SegCtx &sc, double *u, double *v) {
-    const RtPrimGeo &G = L.prim_geo[pi];
+    const RtPrimGeo &G = rec_at(L.prim_geo, pi);
     *u = 0.0;
     *v = 0.0;
     uint32_t kw = (uint32_t)RT_PRIM_SPHERE_T;
-    if (GENERAL || MEDIUM) kw = L.prim_meta[pi].kind;
+    if (GENERAL || MEDIUM) kw = rec_at(L.prim_meta, pi).kind;
     const uint32_t kind = kw & 0xFFu;
     if (kind == RT_PRIM_SPHERE_T) {
         const V3 oc = o - mk(G.g[0], G.g[1], G.g[2]);
@@ -995,7 +1019,7 @@ RT_HD void prim_uv(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double t, SegCtx 
             }
             return;
         }
-        const RtPrimMeta &P = L.prim_meta[pi];
+        const RtPrimMeta &P = rec_at(L.prim_meta, pi);
         V3 lo = o, ld = d;
         chain_down<(MEDIUM >= 2)>(L, P.xform, (kw >> RT_META_CHAIN_SHIFT) & 0xFu, (kw >> RT_META_TMASK_SHIFT) & 0xFu, &lo, &ld);
         if (kind == RT_PRIM_SPHERE_C) {
@@ -1073,9 +1097,9 @@ RT_HD bool finish_segment(const RtLaunch &L, PathState *ps, const Trav &tv, V3 *
     *radiance = mk(0.0, 0.0, 0.0);
     if (tv.best_prim == 0xFFFFFFFFu) return true; // background is black (src/render.rs:21-28)
     const uint32_t prim = tv.best_prim;
-    const uint32_t mat = L.prim_meta[prim].material;
+    const uint32_t mat = (GENERAL || MEDIUM) ? rec_at(L.prim_meta, prim).material : L.prim_meta[prim].material;
     if (mat == RT_NO_MATERIAL) return true; // src/render.rs:18-20
-    const RtMaterial &M = L.materials[mat];
+    const RtMaterial &M = (GENERAL || MEDIUM) ? rec_at(L.materials, mat) : L.materials[mat];
     SegCtx sc;
     sc.r2a = RTL_NAN; // the record is built at the known t: no roots
     sc.rng_base = ps->g.base;

@@ -21,6 +21,7 @@ struct rt_scene {
          *d_materials = nullptr, *d_textures = nullptr, *d_blob = nullptr;
     size_t device_bytes = 0;
     size_t workspace_limit = 0; // rt_scene_set_workspace_limit; 0 = default (rt_api.cpp sample_workspace_cap)
+    size_t workspace_default = 0; // the default, once computed
     std::mutex mu;        // guards the fields below
     std::mutex render_mu; // serialises rt_render calls: they share the sample workspace
     // cached occupancy query of the last kernel variant used

@@ -15,6 +15,7 @@
 #define RT_MAX_CHAIN 4      /* transform levels above one leaf (Sprite > BVH > Sprite > TransformedGeometry ...) every kernel family unrolls */
 #define RT_MAX_CHAIN_DEEP 15 /* levels the family for general media / deep chains walks (the ones beyond RT_MAX_CHAIN in a run-time loop) */
 #define RT_JOB_SPP_MAX 32   /* samples per pixel in one job at most (job = one 8x8 tile x job_spp samples) */
+#define RT_MAX_RECORDS (1u << 24) /* records per scene array: the kernels build 32-bit byte offsets with a 24-bit multiply */
 #define RT_NO_MATERIAL 0xFFFFFFFFu
 #define RT_MAT_KIND_NONE 0xFFu /* in RtPrimMeta::kind bits 8-15: the prim has no material */
 
@@ -77,6 +78,7 @@ struct alignas(16) RtNode {
     uint32_t child[2];               // references in the scene's form, see RT_REF_*
     uint32_t pad[2];
 }; // 64 B
+static_assert(sizeof(RtNode) == 64 && __builtin_offsetof(RtNode, child) == 48, "rtl::trav_node_step reads the planes and children by byte offset");
 
 struct alignas(16) RtPrimMeta {
     uint32_t kind;     // see RT_META_*: prim kind, material kind (the shade block classifies a hit with one load), chain
@@ -131,6 +133,8 @@ struct RtCounters {
     unsigned long long node_cycles, leaf_cycles, shade_cycles, finish_cycles, refill_cycles, begin_cycles;
     // swap-at-shade diagnostics (see include/rt_mi355x.h)
     unsigned long long swap_class_mode, swap_new_mode, swap_parked, swap_pulled, swap_lock_busy, swap_scattered, swap_off_class, swap_cycles;
+    unsigned long long node_idle_done, node_idle_leaf, node_idle_empty;
+    unsigned long long xchg_wave, xchg_parked, xchg_pulled, xchg_pushed;
 };
 
 // kernel arguments (passed by value)

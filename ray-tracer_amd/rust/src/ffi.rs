@@ -59,6 +59,13 @@ pub struct rt_counters {
     pub swap_scattered: u64,
     pub swap_off_class: u64,
     pub swap_cycles: u64,
+    pub node_idle_done: u64,
+    pub node_idle_leaf: u64,
+    pub node_idle_empty: u64,
+    pub xchg_wave: u64,
+    pub xchg_parked: u64,
+    pub xchg_pulled: u64,
+    pub xchg_pushed: u64,
 }
 
 #[repr(C)]
