@@ -300,6 +300,7 @@ int rt_probe_device_math(int device, const double *a, const double *b, int n, do
 #define RT_FEAT_LENS 16u
 #define RT_FEAT_WIDE 64u           /* more than 32767 prims or nodes: 32-bit node references, two LDS words per stack entry */
 #define RT_FEAT_MEDIUM_GENERAL 32u /* a ConstantMedium whose boundary is not a plain sphere under a pure translation */
+#define RT_FEAT_MEDIUM_NESTED 256u  /* a ConstantMedium inside the boundary of another (up to three levels) */
 #define RT_FEAT_DEEP_CHAIN 128u    /* more than four transform levels above a primitive (up to 15): served by the same kernel family */
 
 #ifdef __cplusplus

@@ -123,14 +123,33 @@ RT_HD uint64_t rt_rng_keyed_from_base(uint64_t base, uint32_t segment, uint32_t 
     return rt_mix64(base + n * RT_RNG_GAMMA);
 }
 
-/* Key of the free-flight draws of a ConstantMedium that sits inside instanced geometry (a Sprite whose geometry is a
- * BoundingVolumeHierarchyNode of further sprites): every instance needs draws of its own.  path_hash folds the
- * creation indices of the sprites from the world's list down to the medium's sprite,
- *     h = index(top) + 1;  h = h * RT_RNG_PATH_MUL + index(child) + 1  for every level below,
- * and the key is the low 10 bits of its mix.  A medium sprite of the world's own list keeps its creation-order slot
- * (round-1 results unchanged).  Two media whose keys collide share their draws on a segment (1 pair in 1024). */
+/* ---- keys of the free-flight draws of ConstantMedium::hit (src/volume.rs:58-60, 80-82) ----
+ * The reference draws from the thread's sequential generator in the order its (random) tree visits the media: unpinned
+ * (quirk Q10).  Here every evaluation of a medium on a segment owns a keyed draw, independent of traversal order:
+ *   - a medium sprite of the world's own list (Sprite<ConstantMedium<..>> directly, the reference's own scenes): key = its
+ *     creation-order slot among such sprites, 0 .. RT_MEDIUM_SLOT_MAX - 1, drawn by rt_rng_keyed_from_base (round-1 streams);
+ *   - any other medium (inside a node used as a geometry, behind a TransformedGeometry): a 32-bit key >= 2^31 from the path
+ *     of sprites that leads to it,  h = rank(top) + 1;  h = h * RT_RNG_PATH_MUL + index(child in its node) + 1  per level
+ *     (rank = position among the world's own sprites, index = position in the node's list: independent of the order a front
+ *     end happens to create sprites in), so every instance draws its own numbers;
+ *   - a medium inside the BOUNDARY of another medium (ConstantMedium<T: Hit> with T containing a ConstantMedium,
+ *     src/volume.rs:18-44) is evaluated up to twice per evaluation of the outer one (boundary.hit of the ray, then of the
+ *     restarted ray): key = rt_medium_key_inner(outer key, pass 0 / 1, its own path key).
+ * Wide keys draw from the upper quarter of the stream's keyed window (rt_rng_keyed_wide). */
 #define RT_RNG_PATH_MUL 1000003ull
-RT_HD uint32_t rt_medium_key_nested(uint64_t path_hash) { return (uint32_t)(rt_mix64(path_hash) & 0x3FFull); }
+#define RT_MEDIUM_SLOT_MAX 0x3FFu /* slots 0 .. 0x3FE; 0x3FF marks "no slot" */
+#define RT_MEDIUM_KEY_WIDE 0x400u /* keys from here on are path keys */
+RT_HD uint32_t rt_medium_key_path(uint64_t path_hash) { return (uint32_t)rt_mix64(path_hash) | 0x80000000u; }
+RT_HD uint32_t rt_medium_key_inner(uint32_t outer, uint32_t pass, uint32_t own) {
+    return (uint32_t)rt_mix64((((uint64_t)outer << 32) | (uint64_t)own) * RT_RNG_PATH_MUL + (uint64_t)pass + 1ull) | 0x80000000u;
+}
+RT_HD uint64_t rt_rng_keyed_wide(uint64_t base, uint32_t segment, uint32_t key) {
+    const uint64_t n = RT_RNG_KEYED_BASE + (1ull << 22) + (rt_mix64(((uint64_t)segment << 32) | (uint64_t)key) & 0x3FFFFFull);
+    return rt_mix64(base + n * RT_RNG_GAMMA);
+}
+RT_HD uint64_t rt_rng_medium_draw(uint64_t base, uint32_t segment, uint32_t key) {
+    return key < RT_MEDIUM_KEY_WIDE ? rt_rng_keyed_from_base(base, segment, key) : rt_rng_keyed_wide(base, segment, key);
+}
 
 RT_HD double rt_bits_to_double(uint64_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)

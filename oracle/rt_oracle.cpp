@@ -192,8 +192,10 @@ struct Ctx {
     rt_rng rng;
     uint32_t segment = 0;     // index of the current path segment (keyed medium draws)
     uint32_t medium_slot = 0; // slot of the sprite whose geometry is being tested
-    uint64_t path_hash = 0;   // creation indices of the sprites entered so far, folded (include/rt_rng.h, rt_medium_key_nested)
+    uint64_t path_hash = 0;   // ranks / child indices of the sprites entered so far, folded (include/rt_rng.h, rt_medium_key_path)
     int path_len = 0;         // sprites entered so far: 1 = a sprite of the world's own list
+    int medium_depth = 0;     // ConstantMedium::hit calls in progress (a medium inside another medium's boundary)
+    uint32_t outer_key = 0, outer_pass = 0; // of the innermost one: its key and which of its two boundary.hit calls is running
     orc_counters cnt{0, 0, 0, 0, 0};
     double next53() { // rand::random::<f64>()
         ++cnt.rng_draws;
@@ -207,11 +209,17 @@ struct Ctx {
         ++cnt.rng_draws;
         return rt_rng_range11(&rng);
     }
-    double keyed01() { // ConstantMedium's gen_range(0.0, 1.0): see rt_rng.h
+    // key of the ConstantMedium::hit that starts now (include/rt_rng.h): the creation-order slot for a medium sprite of the
+    // world's own list, else a key from the path of sprites above it; inside another medium's boundary, derived from the outer
+    // evaluation's key and pass as well
+    uint32_t medium_key() const {
+        const bool own_slot = path_len == 1 && medium_slot < RT_MEDIUM_SLOT_MAX;
+        const uint32_t key = own_slot ? medium_slot : rt_medium_key_path(path_hash);
+        return medium_depth == 0 ? key : rt_medium_key_inner(outer_key, outer_pass, rt_medium_key_path(path_hash));
+    }
+    double keyed01(uint32_t key) { // ConstantMedium's gen_range(0.0, 1.0)
         ++cnt.rng_draws;
-        // a medium inside instanced geometry (more than one sprite above it) is keyed by its path: every instance its own draws
-        const uint32_t key = path_len > 1 ? rt_medium_key_nested(path_hash) : medium_slot;
-        return rt_u64_to_range01(rt_rng_keyed_from_base(rng.base, segment, key));
+        return rt_u64_to_range01(rt_rng_medium_draw(rng.base, segment, key));
     }
 };
 
@@ -322,8 +330,10 @@ struct Scene {
     int world_nodes = 0;
     int medium_slots = 0;
     uint64_t n_sprites = 0;
+#ifdef ORC_WITH_HYPOTHESES // the probe library only (oracle/_build/librt_oracle_hyp.so); the parity anchor is compiled without
     double hyp_param = 0.0;
-    unsigned hypothesis = 0; // ORC_HYP_*: earlier forms of the reference's code the cover.png probes try (never a default)
+    unsigned hypothesis = 0; // ORC_HYP_*: earlier forms of the reference's code the cover.png probes try
+#endif
     // camera (camera.rs:10-21)
     Vec3 eye{0, 0, 0}, lowerLeft{0, 0, 0}, horizontal{0, 0, 0}, vertical{0, 0, 0};
     double lensRadius = 0.0;
@@ -381,6 +391,7 @@ struct Dielectric : Material { // material.rs:122-193
             double theta = std::acos(-dot(rayIn.direction, normal));
             double u = c.range01(); // drawn before the probability is evaluated (operand order)
             double pr = schlickReflectionProbability(theta, ratio, 1.0);
+#ifdef ORC_WITH_HYPOTHESES
             if (s.hypothesis) { // cover.png probes only
                 const bool inside = ratio > 1.0;
                 if ((s.hypothesis & ORC_HYP_NO_FRESNEL) || ((s.hypothesis & ORC_HYP_NO_INSIDE_FRESNEL) && inside)) pr = 0.0;
@@ -389,6 +400,7 @@ struct Dielectric : Material { // material.rs:122-193
                     pr = schlickReflectionProbability(std::acos(dot(rn, rec.normal)), ratio, 1.0);
                 }
             }
+#endif
             if (u < pr) {
                 *sc = Ray{rec.intersection, reflected(rayIn.direction, rec.normal)};
             } else {
@@ -411,8 +423,15 @@ struct Isotropic : Material { // material.rs:302-326
     explicit Isotropic(int t) : albedo(t) {}
     bool scatter(const Scene &s, Ctx &c, const Ray &rayIn, const HitRecord &rec, Ray *sc, Vec3 *att) const override {
         Vec3 p = randomInUnitSphere(c);
+#ifdef ORC_WITH_HYPOTHESES
         if (s.hypothesis & ORC_HYP_ISOTROPIC_FORWARD) p = p + rayIn.direction * s.hyp_param; // probe: a forward-biased lobe
-        *sc = Ray{rec.intersection, (s.hypothesis & ORC_HYP_ISOTROPIC_UNNORMALIZED) ? p : normalized(p)}; // probe: the book's listing
+        if (s.hypothesis & ORC_HYP_ISOTROPIC_UNNORMALIZED) {                                 // probe: the book's listing
+            *sc = Ray{rec.intersection, p};
+            *att = s.textures[albedo]->value(s, rec.u, rec.v, rec.intersection);
+            return true;
+        }
+#endif
+        *sc = Ray{rec.intersection, normalized(p)};
         *att = s.textures[albedo]->value(s, rec.u, rec.v, rec.intersection);
         return true;
     }
@@ -550,15 +569,39 @@ struct ConstantMedium : Object { // volume.rs:18-101
     ConstantMedium(int b, double d) : boundary(b), density(d) {}
     bool hit(const Scene &s, Ctx &c, const Ray &ray, HitRecord *rec) const override { // volume.rs:46-100
         const Object &bnd = *s.geometries[boundary];
+        // the boundary may hold media of its own (T: Hit is generic, volume.rs:18-44): they key their draws from this evaluation
+        const uint32_t key = c.medium_key();
+        struct Scope {
+            Ctx &c;
+            int depth;
+            uint32_t key, pass;
+            Scope(Ctx &cc, uint32_t k) : c(cc), depth(cc.medium_depth), key(cc.outer_key), pass(cc.outer_pass) {
+                ++c.medium_depth;
+                c.outer_key = k;
+                c.outer_pass = 0;
+            }
+            ~Scope() {
+                c.medium_depth = depth;
+                c.outer_key = key;
+                c.outer_pass = pass;
+            }
+        };
         HitRecord record1;
-        if (!bnd.hit(s, c, ray, &record1)) return false;
+        {
+            Scope scope(c, key);
+            if (!bnd.hit(s, c, ray, &record1)) return false;
+        }
         if (dot(record1.normal, ray.direction) < 0.0) {
             // entering: restart just inside
             Ray ray2{record1.intersection + ray.direction * 1e-6, ray.direction};
             HitRecord record2;
-            if (!bnd.hit(s, c, ray2, &record2)) return false;
+            {
+                Scope scope(c, key);
+                c.outer_pass = 1;
+                if (!bnd.hit(s, c, ray2, &record2)) return false;
+            }
             double distanceInsideGeometry = record2.t;
-            double distance = (-1.0 / density) * std::log(c.keyed01());
+            double distance = (-1.0 / density) * std::log(c.keyed01(key));
             if (distance > distanceInsideGeometry) return false;
             rec->u = record1.u + record2.u;
             rec->v = record1.v + record2.v;
@@ -569,16 +612,20 @@ struct ConstantMedium : Object { // volume.rs:18-101
             return true;
         }
         // origin inside the boundary
+#ifdef ORC_WITH_HYPOTHESES
         if (s.hypothesis & ORC_HYP_INSIDE_NONE) return false; // the book's listing as the reference's comment reads it (volume.rs:44-45)
+#endif
         double distanceInsideGeometry = record1.t;
-        double distance = (-1.0 / density) * std::log(c.keyed01());
+        double distance = (-1.0 / density) * std::log(c.keyed01(key));
         if (distance > distanceInsideGeometry) return false;
         rec->u = record1.u;
         rec->v = record1.v;
         rec->t = distance; // volume.rs:90 "written wrong originally"
         rec->intersection = ray.at(distance);
+#ifdef ORC_WITH_HYPOTHESES
         if (s.hypothesis & ORC_HYP_INSIDE_T_ADDS_T1) rec->t = record1.t + distance;
         if (s.hypothesis & ORC_HYP_INSIDE_POINT_ADDS_T1) rec->intersection = ray.at(record1.t + distance);
+#endif
         rec->normal = record1.normal;
         rec->material = -1;
         return true;
@@ -598,14 +645,16 @@ struct Sprite : Object { // sprite.rs:11-139
     int geometry, material; // Option<Arc<T>>, Option<Arc<U>>
     Mat4Cached transform;
     uint32_t medium_slot = 0x3FFu;
-    uint64_t sid = 0; // creation index among the sprites
+    uint64_t sid = 0;      // creation index among the sprites
+    uint64_t place = 0;    // position among the world's own sprites, or in the list of the node that owns it (path keys, rt_rng.h)
+    bool owned = false;    // moved into a node used as a geometry
     Sprite(int g, int m, const Mat4 &t) : geometry(g), material(m), transform(t) {}
     bool hit(const Scene &s, Ctx &c, const Ray &ray, HitRecord *rec) const override { // sprite.rs:94-138
         if (geometry < 0) return false;
         const uint32_t saved = c.medium_slot;
         const uint64_t saved_hash = c.path_hash;
         c.medium_slot = medium_slot;
-        c.path_hash = c.path_len == 0 ? sid + 1ull : c.path_hash * RT_RNG_PATH_MUL + sid + 1ull;
+        c.path_hash = c.path_len == 0 ? place + 1ull : c.path_hash * RT_RNG_PATH_MUL + place + 1ull;
         ++c.path_len;
         bool ok = transformed_hit(transform, ray, rec,
                                   [&](const Ray &r, HitRecord *lr) { return s.geometries[geometry]->hit(s, c, r, lr); });
@@ -887,8 +936,10 @@ extern "C" {
 orc_scene *orc_scene_new(void) { return new orc_scene; }
 void orc_scene_free(orc_scene *p) { delete p; }
 
+#ifdef ORC_WITH_HYPOTHESES
 void orc_set_hypothesis(orc_scene *p, unsigned flags) { p->s.hypothesis = flags; }
 void orc_set_hypothesis_param(orc_scene *p, double v) { p->s.hyp_param = v; }
+#endif
 int orc_tex_solid(orc_scene *p, double r, double g, double b) {
     p->s.textures.emplace_back(new SolidColor(v3(r, g, b)));
     return (int)p->s.textures.size() - 1;
@@ -942,9 +993,7 @@ int orc_sprite(orc_scene *p, int geometry, int material, const double *M) {
     if (M) std::memcpy(m.a, M, sizeof m.a);
     Sprite *sp = new Sprite(geometry, material, m);
     sp->sid = p->s.n_sprites++;
-    if (geometry >= 0 && dynamic_cast<ConstantMedium *>(p->s.geometries[geometry].get())) {
-        sp->medium_slot = (uint32_t)(p->s.medium_slots++) & 0x3FFu;
-    }
+    // (medium_slot is assigned when the world is built: rank_world_sprites)
     p->s.objects.emplace_back(sp);
     return (int)p->s.objects.size() - 1;
 }
@@ -953,7 +1002,28 @@ static std::vector<const Object *> gather(orc_scene *p, const int *objects, int 
     for (int i = 0; i < n; ++i) v.push_back(p->s.objects[objects[i]].get());
     return v;
 }
+// positions of the world's own sprites among themselves, in creation order (the product's world list)
+// ... and the creation-order slots of the medium sprites among them (keys of their draws, include/rt_rng.h)
+static void rank_world_sprites(orc_scene *p) {
+    uint64_t r = 0;
+    int slots = 0;
+    for (auto &o : p->s.objects)
+        if (Sprite *sp = dynamic_cast<Sprite *>(o.get())) {
+            sp->medium_slot = 0x3FFu;
+            if (sp->owned) continue;
+            sp->place = r++;
+            if (sp->geometry >= 0 && dynamic_cast<ConstantMedium *>(p->s.geometries[sp->geometry].get())) {
+                const int slot = slots++;
+                if (slot < (int)RT_MEDIUM_SLOT_MAX) sp->medium_slot = (uint32_t)slot; // beyond: a path key (the product refuses such scenes)
+            }
+        }
+}
 int orc_geom_bvh(orc_scene *p, const int *objects, int n, uint64_t seed) {
+    for (int i = 0; i < n; ++i)
+        if (Sprite *sp = dynamic_cast<Sprite *>(p->s.objects[objects[i]].get())) {
+            sp->owned = true;
+            sp->place = (uint64_t)i;
+        }
     rt_rng g;
     rt_rng_init(&g, seed, RT_RNG_SCENE_STREAM);
     auto node = BVHNode::make(p->s, gather(p, objects, n), &g);
@@ -976,6 +1046,7 @@ int orc_object_bvh(orc_scene *p, const int *objects, int n, uint64_t seed) {
     return (int)p->s.objects.size() - 1;
 }
 int orc_world_bvh(orc_scene *p, const int *objects, int n, uint64_t seed) {
+    rank_world_sprites(p);
     rt_rng g;
     rt_rng_init(&g, seed, RT_RNG_SCENE_STREAM);
     auto node = BVHNode::make(p->s, gather(p, objects, n), &g);
@@ -985,6 +1056,7 @@ int orc_world_bvh(orc_scene *p, const int *objects, int n, uint64_t seed) {
     return 0;
 }
 int orc_world_list(orc_scene *p, const int *objects, int n) {
+    rank_world_sprites(p);
     ObjectList *l = new ObjectList;
     l->items = gather(p, objects, n);
     p->s.world.reset(l);

@@ -37,8 +37,11 @@ typedef struct orc_scene orc_scene;
 orc_scene *orc_scene_new(void);
 void orc_scene_free(orc_scene *);
 
-/* cover.png probes only (tools/blue_hypotheses.py): earlier forms of ConstantMedium::hit that the reference's own
- * comments hint at.  Never set by tests that pin parity; the product has no counterpart. */
+/* cover.png probes only (tools/blue_hypotheses.py): earlier forms of ConstantMedium::hit / Dielectric / Isotropic that the
+ * reference's own comments hint at.  Compiled ONLY into the second, probe-only library oracle/_build/librt_oracle_hyp.so
+ * (-DORC_WITH_HYPOTHESES): librt_oracle.so -- the parity anchor of every test and the timed CPU baseline -- is the plain
+ * restatement and exports neither function (tests/test_oracle_kat.py checks).  The product has no counterpart. */
+#ifdef ORC_WITH_HYPOTHESES
 #define ORC_HYP_INSIDE_T_ADDS_T1 1u     /* origin-inside branch: t = record1.t + distance (src/volume.rs:90 "written wrong originally") */
 #define ORC_HYP_INSIDE_POINT_ADDS_T1 2u /* ... and the point taken at that t */
 #define ORC_HYP_INSIDE_NONE 4u          /* origin-inside branch returns None, the book's listing (comment at src/volume.rs:44-45) */
@@ -49,6 +52,7 @@ void orc_scene_free(orc_scene *);
 #define ORC_HYP_ISOTROPIC_FORWARD 128u       /* Isotropic::scatter direction = normalize(randomInUnitSphere() + param * d_in) */
 void orc_set_hypothesis(orc_scene *, unsigned flags);
 void orc_set_hypothesis_param(orc_scene *, double value);
+#endif
 
 /* textures (src/material.rs:196-271) -> texture id */
 int orc_tex_solid(orc_scene *, double r, double g, double b);

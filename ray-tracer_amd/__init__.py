@@ -28,6 +28,7 @@ RT_TILE = 8
 RT_FLAG_COUNTERS = 1
 RT_FEAT_SPHERE_T, RT_FEAT_GENERAL, RT_FEAT_MEDIUM, RT_FEAT_TEXTURED, RT_FEAT_LENS, RT_FEAT_MEDIUM_GENERAL, RT_FEAT_WIDE = 1, 2, 4, 8, 16, 32, 64
 RT_FEAT_DEEP_CHAIN = FEAT_DEEP_CHAIN = 128
+RT_FEAT_MEDIUM_NESTED = 256
 ERR_INVALID, ERR_EMPTY, ERR_DEVICE, ERR_UNSUPPORTED, ERR_STATE = -1, -2, -3, -4, -5  # include/rt_mi355x.h RT_ERR_*
 
 

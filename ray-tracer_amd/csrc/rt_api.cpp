@@ -183,8 +183,6 @@ int rt_add_geometry_cube(rt_scene *s, double w, double h, double d) { return add
 int rt_add_geometry_constant_medium(rt_scene *s, int boundary, double density) {
     RT_RECORDING(s);
     if (boundary < 0 || (size_t)boundary >= s->ir.geometries.size()) return fail(RT_ERR_INVALID, "medium: unknown boundary geometry");
-    if (s->ir.geometries[(size_t)boundary].kind == rt::GEO_MEDIUM)
-        return fail(RT_ERR_UNSUPPORTED, "medium: the boundary of a ConstantMedium cannot itself be a ConstantMedium");
     return add_geometry_locked(s, rt::GEO_MEDIUM, density, 0, 0, boundary);
 }
 int rt_add_geometry_transformed(rt_scene *s, int geometry, const double M[16]) {

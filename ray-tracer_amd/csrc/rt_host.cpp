@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <numeric>
 
@@ -356,9 +357,11 @@ bool make_link(const double M[16], Link *l) {
 
 // a sphere or rectangle under its chain, before it becomes a BVH leaf or a medium's boundary prim
 struct Shape {
-    uint32_t kind; // RT_PRIM_SPHERE_C / RT_PRIM_RECT_C
-    double a, b;   // r | w, h
+    uint32_t kind; // RT_PRIM_SPHERE_C / RT_PRIM_RECT_C / RT_PRIM_MEDIUM_C (a medium inside a medium's boundary)
+    double a, b;   // r | w, h | density
     std::vector<Link> chain; // outermost first
+    std::vector<Shape> inner; // RT_PRIM_MEDIUM_C: its own boundary, chains relative to this medium's frame
+    uint32_t key = 0;         // RT_PRIM_MEDIUM_C: rt_medium_key_path of the sprites that lead to it (include/rt_rng.h)
 };
 struct Leaf {
     RtPrimMeta meta{};
@@ -417,15 +420,16 @@ struct Flattener {
     }
 
     // every sphere / rectangle below geometry `gi`, each with the transforms between it and `chain`'s end appended
-    bool collect_shapes(int gi, std::vector<Link> chain, std::vector<Shape> *out, int depth) {
+    // path_hash: the sprites from the world's list down to here (keys of nested media); media: ConstantMedium levels entered so far
+    bool collect_shapes(int gi, std::vector<Link> chain, std::vector<Shape> *out, int depth, uint64_t path_hash = 0, int media = 1) {
         if (depth > 16) return fail(RT_ERR_UNSUPPORTED, "geometry nesting deeper than 16 levels");
         const GeometryIR &g = ir.geometries[(size_t)gi];
         switch (g.kind) {
         case GEO_SPHERE:
-            out->push_back(Shape{RT_PRIM_SPHERE_C, g.p[0], 0.0, chain});
+            out->push_back(Shape{RT_PRIM_SPHERE_C, g.p[0], 0.0, chain, {}, 0u});
             return true;
         case GEO_RECTANGLE:
-            out->push_back(Shape{RT_PRIM_RECT_C, g.p[0], g.p[1], chain});
+            out->push_back(Shape{RT_PRIM_RECT_C, g.p[0], g.p[1], chain, {}, 0u});
             return true;
         case GEO_CUBE: { // BoundingVolumeHierarchyNode::new(Cube::new(w, h, d)): six TransformedGeometry<Rectangle>
             CubeFace f[6];
@@ -435,7 +439,7 @@ struct Flattener {
                 if (!make_link(face.M, &l)) continue;
                 std::vector<Link> c = chain;
                 c.push_back(l);
-                out->push_back(Shape{RT_PRIM_RECT_C, face.w, face.h, c});
+                out->push_back(Shape{RT_PRIM_RECT_C, face.w, face.h, c, {}, 0u});
             }
             return true;
         }
@@ -443,23 +447,57 @@ struct Flattener {
             Link l;
             if (!make_link(g.M, &l)) return true; // never hit
             chain.push_back(l);
-            return collect_shapes(g.boundary, chain, out, depth + 1);
+            return collect_shapes(g.boundary, chain, out, depth + 1, path_hash, media);
         }
         case GEO_BVH:
-            for (int si : g.children) {
-                const SpriteIR &sp = ir.sprites[(size_t)si];
+            for (size_t k = 0; k < g.children.size(); ++k) {
+                const SpriteIR &sp = ir.sprites[(size_t)g.children[k]];
                 if (sp.geometry < 0) continue;
                 Link l;
                 if (!make_link(sp.M, &l)) continue;
                 std::vector<Link> c = chain;
                 c.push_back(l);
-                if (!collect_shapes(sp.geometry, c, out, depth + 1)) return false;
+                if (!collect_shapes(sp.geometry, c, out, depth + 1, path_hash * RT_RNG_PATH_MUL + (uint64_t)k + 1ull, media)) return false;
             }
             return true;
-        case GEO_MEDIUM:
-            return fail(RT_ERR_UNSUPPORTED, "a ConstantMedium inside the boundary of another ConstantMedium is not supported");
+        case GEO_MEDIUM: {
+            // ConstantMedium<T: Hit> with a ConstantMedium inside T (src/volume.rs:18-44): a boundary prim that is itself a
+            // medium, evaluated (with draws of its own) by each of the outer medium's two boundary.hit calls
+            if (media >= RT_MAX_MEDIUM_NESTING)
+                return fail(RT_ERR_UNSUPPORTED, "more than RT_MAX_MEDIUM_NESTING (3) ConstantMedium levels inside one another");
+            if (chain.size() > RT_MAX_CHAIN_DEEP)
+                return fail(RT_ERR_UNSUPPORTED, "more than RT_MAX_CHAIN_DEEP (15) transform levels inside a medium's boundary");
+            Shape m{RT_PRIM_MEDIUM_C, g.p[0], 0.0, chain, {}, rt_medium_key_path(path_hash)};
+            if (!collect_shapes(g.boundary, {}, &m.inner, depth + 1, path_hash, media + 1)) return false;
+            for (const Shape &sh : m.inner)
+                if (sh.chain.size() > RT_MAX_CHAIN_DEEP)
+                    return fail(RT_ERR_UNSUPPORTED, "more than RT_MAX_CHAIN_DEEP (15) transform levels inside a medium's boundary");
+            if (!m.inner.empty()) out->push_back(std::move(m)); // an empty boundary is never hit
+            fs.feature_mask |= RT_FEAT_MEDIUM_NESTED;
+            return true;
+        }
         }
         return true;
+    }
+
+    // the AABB of everything a boundary can report a hit in, carried through `outer` (a nested medium hits inside its own boundary)
+    Aabb boundary_bound(const std::vector<Shape> &shapes, const std::vector<Link> &outer, bool *any) {
+        Aabb acc{};
+        for (const Shape &sh : shapes) {
+            Aabb sb;
+            if (sh.kind == RT_PRIM_MEDIUM_C) {
+                std::vector<Link> o = outer;
+                o.insert(o.end(), sh.chain.begin(), sh.chain.end());
+                bool sub = false;
+                sb = boundary_bound(sh.inner, o, &sub);
+                if (!sub) continue;
+            } else {
+                sb = chain_bound(shape_local_bound(sh), outer, sh.chain);
+            }
+            acc = *any ? merged(acc, sb) : sb;
+            *any = true;
+        }
+        return acc;
     }
 
     // Does `gi`, seen from the frame of the ConstantMedium around it, enclose a volume whose FIRST hit from outside always
@@ -550,14 +588,15 @@ struct Flattener {
             return emit(g.boundary, c, material, path_hash, path_len, top_slot, depth + 1);
         }
         case GEO_BVH:
-            for (int si : g.children) {
-                const SpriteIR &sp = ir.sprites[(size_t)si];
+            for (size_t k = 0; k < g.children.size(); ++k) {
+                const SpriteIR &sp = ir.sprites[(size_t)g.children[k]];
                 if (sp.geometry < 0) continue; // geometry None: never hit (src/sprite.rs:95,136)
                 Link l;
                 if (!make_link(sp.M, &l)) continue;
                 std::vector<Link> c = chain;
                 c.push_back(l);
-                if (!emit(sp.geometry, c, material, path_hash * RT_RNG_PATH_MUL + (uint64_t)si + 1ull, path_len + 1, top_slot, depth + 1))
+                // the child's position in its node, not its creation index: independent of the order a front end records sprites in
+                if (!emit(sp.geometry, c, material, path_hash * RT_RNG_PATH_MUL + (uint64_t)k + 1ull, path_len + 1, top_slot, depth + 1))
                     return false;
             }
             return true;
@@ -568,8 +607,9 @@ struct Flattener {
             Leaf lf;
             lf.meta.material = material;
             lf.chain = chain;
-            // a medium sprite of the world's own list keeps its creation-order slot; a nested one is keyed by its path
-            lf.meta.aux = path_len == 1 ? top_slot : rt_medium_key_nested(path_hash);
+            // a medium sprite of the world's own list keeps its creation-order slot; any other one is keyed by its path
+            // (include/rt_rng.h): inside a node, behind a TransformedGeometry
+            lf.meta.aux = (path_len == 1 && top_slot < RT_MEDIUM_SLOT_MAX) ? top_slot : rt_medium_key_path(path_hash);
             const GeometryIR &b = ir.geometries[(size_t)g.boundary];
             fs.feature_mask |= RT_FEAT_MEDIUM;
             // a medium whose material reads uv (src/volume.rs:64-66: the sums over both boundary hits) goes to the kernel
@@ -587,16 +627,13 @@ struct Flattener {
             } else {
                 lf.meta.kind = RT_PRIM_MEDIUM_C;
                 lf.geo.g[0] = g.p[0];
-                if (!collect_shapes(g.boundary, {}, &lf.boundary, depth + 1)) return false;
-                bool first = true;
-                for (const Shape &sh : lf.boundary) {
+                if (!collect_shapes(g.boundary, {}, &lf.boundary, depth + 1, path_hash, 1)) return false;
+                for (const Shape &sh : lf.boundary)
                     if (sh.chain.size() > RT_MAX_CHAIN_DEEP)
                         return fail(RT_ERR_UNSUPPORTED, "more than RT_MAX_CHAIN_DEEP (15) transform levels inside a medium's boundary");
-                    const Aabb sb = chain_bound(shape_local_bound(sh), chain, sh.chain);
-                    lf.bound = first ? sb : merged(lf.bound, sb);
-                    first = false;
-                }
-                if (first) return true; // empty boundary: never hit
+                bool any = false;
+                lf.bound = boundary_bound(lf.boundary, chain, &any);
+                if (!any) return true; // empty boundary: never hit
                 lf.unbounded = !boundary_encloses(g.boundary, depth + 1);
                 fs.feature_mask |= RT_FEAT_GENERAL | RT_FEAT_MEDIUM_GENERAL;
             }
@@ -664,18 +701,26 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
     // the world's own sprites -> leaves, in creation order (hoisted ones are moved to the front below); a sprite whose
     // geometry is a node of further sprites is expanded, every leaf keeping the transforms of all levels above it
     Flattener fl{ir, fs};
+    uint64_t rank = 0; // position among the world's own sprites
     for (size_t si = 0; si < ir.sprites.size(); ++si) {
         const SpriteIR &s = ir.sprites[si];
-        // slots count the medium sprites in creation order, wherever they end up; a sprite that reaches a medium only
-        // through a TransformedGeometry has none (0x3FF)
-        uint32_t slot = 0x3FFu;
-        if (s.geometry >= 0 && ir.geometries[(size_t)s.geometry].kind == GEO_MEDIUM) slot = (fl.medium_slots++) & 0x3FFu;
         if (s.owned) continue;        // moved into a BoundingVolumeHierarchyNode geometry
+        const uint64_t my_rank = rank++;
+        // slots count the medium sprites of the world's own list in creation order; a sprite that reaches a medium only
+        // through a TransformedGeometry has none (0x3FF) and its medium is keyed by its path
+        uint32_t slot = 0x3FFu;
+        if (s.geometry >= 0 && ir.geometries[(size_t)s.geometry].kind == GEO_MEDIUM) {
+            slot = fl.medium_slots++;
+            if (slot >= RT_MEDIUM_SLOT_MAX) {
+                if (err) *err = "more than 1023 ConstantMedium sprites in the world's own list";
+                return RT_ERR_UNSUPPORTED;
+            }
+        }
         if (s.geometry < 0) continue; // geometry None: never hit (src/sprite.rs:95,136)
         Link l;
         if (!make_link(s.M, &l)) continue; // det == 0: unhittable (src/sprite.rs:131-134)
         const uint32_t material = s.material < 0 ? RT_NO_MATERIAL : (uint32_t)s.material;
-        if (!fl.emit(s.geometry, {l}, material, (uint64_t)si + 1ull, 1, slot, 0)) {
+        if (!fl.emit(s.geometry, {l}, material, my_rank + 1ull, 1, slot, 0)) {
             if (err) *err = fl.error;
             return fl.rc;
         }
@@ -767,17 +812,18 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
     }
     fs.n_leaf_prims = (int)fs.prim_meta.size();
 
-    // boundary prims of the general media (never BVH leaves)
-    for (size_t k = 0; k < final_order.size(); ++k) {
-        const Leaf &lf = leaves[final_order[k]];
-        if ((lf.meta.kind & 0xFFu) != RT_PRIM_MEDIUM_C) continue;
-        fs.prim_geo[k].g[1] = (double)fs.prim_meta.size();
-        fs.prim_geo[k].g[2] = (double)lf.boundary.size();
-        for (const Shape &sh : lf.boundary) {
+    // boundary prims of the general media (never BVH leaves): each medium's list is contiguous; a boundary prim that is itself
+    // a medium points at its own list further on
+    std::function<void(size_t, const std::vector<Shape> &)> emit_boundary = [&](size_t owner, const std::vector<Shape> &shapes) {
+        const size_t first = fs.prim_meta.size();
+        fs.prim_geo[owner].g[1] = (double)first;
+        fs.prim_geo[owner].g[2] = (double)shapes.size();
+        for (const Shape &sh : shapes) {
             RtPrimMeta c{};
             c.kind = sh.kind;
             c.material = RT_NO_MATERIAL;
             c.xform = push_chain(fs, sh.chain);
+            c.aux = sh.key;
             fl.finish_meta(&c, sh.chain);
             RtPrimGeo cg{};
             cg.g[0] = sh.a;
@@ -787,6 +833,12 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
             fs.prim_extra.push_back(RtPrimExtra{});
             fs.prim_bounds.push_back(Aabb{{0, 0, 0}, {0, 0, 0}});
         }
+        for (size_t k = 0; k < shapes.size(); ++k)
+            if (shapes[k].kind == RT_PRIM_MEDIUM_C) emit_boundary(first + k, shapes[k].inner);
+    };
+    for (size_t k = 0; k < final_order.size(); ++k) {
+        const Leaf &lf = leaves[final_order[k]];
+        if ((lf.meta.kind & 0xFFu) == RT_PRIM_MEDIUM_C) emit_boundary(k, lf.boundary);
     }
 
     // BVH over the non-hoisted leaves

@@ -505,10 +505,24 @@ RT_HD bool shape_hit(uint32_t kind, const RtPrimGeo &G, V3 lo, V3 ld, bool uv, R
     return rect_hit(lo, ld, G.g[0], G.g[1], r); // RT_PRIM_RECT_C
 }
 
-// ---- ConstantMedium<T: Hit>::hit over any boundary (src/volume.rs:40-100): the boundary's spheres / rectangles
+// ---- ConstantMedium<T: Hit>::hit over any boundary (src/volume.rs:40-100): the boundary's spheres / rectangles / media
 // prims [first, first + count), each under its own chain below the medium; boundary.hit = their nearest hit,
-// strict <, the earlier one wins ties (src/geometry.rs:76-116, src/optimize.rs:469-498)
-RT_HD bool medium_general_hit(const RtLaunch &L, const RtPrimGeo &G, V3 o, V3 d, uint64_t rng_base, uint32_t segment, uint32_t slot,
+// strict <, the earlier one wins ties (src/geometry.rs:76-116, src/optimize.rs:469-498).
+// A boundary prim may itself be a ConstantMedium (T: Hit is generic, src/volume.rs:18-44): it is evaluated -- with a draw of
+// its own, keyed by this evaluation's key and pass (include/rt_rng.h) -- by each of the two boundary.hit calls.  NEST = levels
+// of media that may still follow below this one (the host bounds the nesting to RT_MAX_MEDIUM_NESTING).
+template <int NEST>
+RT_HD bool medium_general_hit(const RtLaunch &L, const RtPrimGeo &G, V3 o, V3 d, uint64_t rng_base, uint32_t segment, uint32_t key,
+                              unsigned long long *draws, unsigned long long *tests, bool uv, Rec *r);
+// a medium inside a medium's boundary: a real call (rare, and inlining three copies of the evaluation into each other triples the
+// slow kernel family's code)
+template <int NEST>
+RT_COLD bool medium_nested_call(const RtLaunch &L, const RtPrimGeo &G, V3 o, V3 d, uint64_t rng_base, uint32_t segment, uint32_t key,
+                                unsigned long long *draws, unsigned long long *tests, bool uv, Rec *r) {
+    return medium_general_hit<NEST>(L, G, o, d, rng_base, segment, key, draws, tests, uv, r);
+}
+template <int NEST>
+RT_HD bool medium_general_hit(const RtLaunch &L, const RtPrimGeo &G, V3 o, V3 d, uint64_t rng_base, uint32_t segment, uint32_t key,
                               unsigned long long *draws, unsigned long long *tests, bool uv, Rec *r) {
     const double density = G.g[0];
     const uint32_t first = (uint32_t)G.g[1], count = (uint32_t)G.g[2];
@@ -519,13 +533,24 @@ RT_HD bool medium_general_hit(const RtLaunch &L, const RtPrimGeo &G, V3 o, V3 d,
         bool have = false;
         for (uint32_t k = 0; k < count; ++k) {
             const uint32_t ci = first + k;
-            const uint32_t kw = rec_at(L.prim_meta, ci).kind;
-            const uint32_t cf = rec_at(L.prim_meta, ci).xform, cl = (kw >> RT_META_CHAIN_SHIFT) & 0xFu, cm = (kw >> RT_META_TMASK_SHIFT) & 0xFu;
+            const RtPrimMeta &CM = rec_at(L.prim_meta, ci);
+            const uint32_t kw = CM.kind;
+            const uint32_t cf = CM.xform, cl = (kw >> RT_META_CHAIN_SHIFT) & 0xFu, cm = (kw >> RT_META_TMASK_SHIFT) & 0xFu;
             V3 co = ro, cd = d;
             chain_down<true>(L, cf, cl, cm, &co, &cd);
             Rec cr;
             ++*tests;
-            if (shape_hit<true>(kw & 0xFFu, rec_at(L.prim_geo, ci), co, cd, uv, &cr) && (!have || cr.t < best.t)) {
+            bool hit;
+            if ((kw & 0xFFu) == RT_PRIM_MEDIUM_C) {
+                if constexpr (NEST > 0)
+                    hit = medium_nested_call<NEST - 1>(L, rec_at(L.prim_geo, ci), co, cd, rng_base, segment,
+                                                       rt_medium_key_inner(key, (uint32_t)pass, CM.aux), draws, tests, uv, &cr);
+                else
+                    hit = false; // (the host refuses deeper nesting)
+            } else {
+                hit = shape_hit<true>(kw & 0xFFu, rec_at(L.prim_geo, ci), co, cd, uv, &cr);
+            }
+            if (hit && (!have || cr.t < best.t)) {
                 chain_up<true>(L, cf, cl, cm, &cr);
                 best = cr;
                 have = true;
@@ -543,7 +568,7 @@ RT_HD bool medium_general_hit(const RtLaunch &L, const RtPrimGeo &G, V3 o, V3 d,
     if (dot(r1.n, d) < 0.0) {
         const double inside = r2.t;
         ++*draws;
-        const double distance = (-1.0 / density) * log_cold(rt_u64_to_range01(rt_rng_keyed_from_base(rng_base, segment, slot)));
+        const double distance = (-1.0 / density) * log_cold(rt_u64_to_range01(rt_rng_medium_draw(rng_base, segment, key)));
         if (distance > inside) return false;
         r->u = r1.u + r2.u;
         r->v = r1.v + r2.v;
@@ -554,7 +579,7 @@ RT_HD bool medium_general_hit(const RtLaunch &L, const RtPrimGeo &G, V3 o, V3 d,
     }
     const double inside = r1.t;
     ++*draws;
-    const double distance = (-1.0 / density) * log_cold(rt_u64_to_range01(rt_rng_keyed_from_base(rng_base, segment, slot)));
+    const double distance = (-1.0 / density) * log_cold(rt_u64_to_range01(rt_rng_medium_draw(rng_base, segment, key)));
     if (distance > inside) return false;
     r->u = r1.u;
     r->v = r1.v;
@@ -605,7 +630,7 @@ RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx
         chain_down<(MEDIUM >= 2)>(L, first, len, tmask, &lo, &ld);
         bool ok;
         if (MEDIUM >= 2 && kind == RT_PRIM_MEDIUM_C)
-            ok = medium_general_hit(L, G, lo, ld, sc.rng_base, sc.segment, P.aux, &sc.draws, &sc.prims_tested, uv, r);
+            ok = medium_general_hit<RT_MAX_MEDIUM_NESTING - 1>(L, G, lo, ld, sc.rng_base, sc.segment, P.aux, &sc.draws, &sc.prims_tested, uv, r);
         else
             ok = shape_hit<RECORD>(kind, G, lo, ld, uv, r);
         if (!ok) return false;

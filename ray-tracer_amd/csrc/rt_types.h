@@ -14,6 +14,7 @@
 #define RT_LIST_BOX_FLOATS 9 /* one list box: {lo, hi, lo} per axis -- entry plane at [s], exit plane at [s + 1], s = sign bit of 1/d */
 #define RT_MAX_CHAIN 4      /* transform levels above one leaf (Sprite > BVH > Sprite > TransformedGeometry ...) every kernel family unrolls */
 #define RT_MAX_CHAIN_DEEP 15 /* levels the family for general media / deep chains walks (the ones beyond RT_MAX_CHAIN in a run-time loop) */
+#define RT_MAX_MEDIUM_NESTING 3 /* ConstantMedium levels inside one another (a medium in the boundary of a medium in ...) */
 #define RT_JOB_SPP_MAX 32   /* samples per pixel in one job at most (job = one 8x8 tile x job_spp samples) */
 #define RT_MAX_RECORDS (1u << 24) /* records per scene array: the kernels build 32-bit byte offsets with a 24-bit multiply */
 #define RT_NO_MATERIAL 0xFFFFFFFFu

@@ -420,3 +420,41 @@ def deep_chains(aspect: float = 1.0, seed: int = 1) -> SceneDesc:
     d.world = [s1, s2, s3, s4, s5, floor, lamp, sky]
     d.camera = ((0.0, 3.0, -9.0), (0.0, 1.6, 1.0), (0.0, 1.0, 0.0), radians(42.0), float(aspect), 10.0, 0.0)
     return d
+
+
+def nested_media(aspect: float = 1.0, seed: int = 1) -> SceneDesc:
+    """Not one of the reference's examples: ConstantMedium<T: Hit> with a ConstantMedium inside T (src/volume.rs:18-44 is generic
+    over the boundary).  The outer medium's two boundary.hit calls each evaluate the inner one with a draw of its own, so the
+    "boundary" it sees is a random surface inside the inner boundary.  (1) a medium whose boundary IS a medium over a sphere, on a
+    sprite of the world's own list; (2) a medium over a node that holds a solid sphere and a medium over a rotated cube; (3) three
+    levels behind a TransformedGeometry; (4) the same node as (2) instanced a second time (keys per instance)."""
+    d = SceneDesc(name="nested-media")
+    g = HostRng(seed)
+    ex, ey, ez = (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)
+
+    def tr(t, rad=0.0, axis=ey):
+        return mat4_multiplied(mat4_translation(t), mat4_rotation(rad, axis))
+
+    white = d.lambertian_rgb((0.73, 0.73, 0.73))
+    light_smoke = d.mat("isotropic", d.tex_solid((0.9, 0.85, 0.8)))
+    dark_smoke = d.mat("isotropic", d.tex_solid((0.15, 0.2, 0.3)))
+    d.textures.append(("checker", d.tex_solid((0.1, 0.1, 0.4)), d.tex_solid((0.9, 0.9, 0.9))))
+    checker_smoke = d.mat("isotropic", len(d.textures) - 1)
+    # (1) medium over a medium over a sphere, directly on a world sprite
+    m1 = d.sprite(d.geom("medium", d.geom("medium", d.geom("sphere", 1.0), 2.0), 0.8), light_smoke, mat4_translation((-2.6, 1.2, 0.4)))
+    # (2) a node of {solid sphere, medium over a rotated cube} as the boundary
+    kids = [d.sprite(d.geom("sphere", 0.7), None, mat4_translation((-0.5, 0.0, 0.0))),
+            d.sprite(d.geom("medium", d.geom("cube", 1.1, 1.3, 0.9), 1.7), None, tr((0.6, 0.1, 0.1), g.gen_range(0.2, 0.6), ey))]
+    node = d.geom("bvh", kids)
+    m2 = d.sprite(d.geom("medium", node, 0.6), dark_smoke, tr((0.2, 1.3, 0.6), -0.4, ez))
+    # (3) three levels behind a TransformedGeometry, textured
+    deep = d.geom("medium", d.geom("medium", d.geom("medium", d.geom("sphere", 0.9), 3.0), 1.5), 0.7)
+    m3 = d.sprite(d.geom("transformed", deep, tr((0.0, 0.2, 0.0), 0.5, ex)), checker_smoke, tr((2.7, 1.1, 0.8), 0.3, ey))
+    # (4) the boundary node of (2) under a second medium geometry and another matrix
+    m4 = d.sprite(d.geom("medium", node, 1.1), light_smoke, tr((0.3, 3.6, 1.8), 0.9, ex))
+    floor = d.sprite(d.geom("rectangle", 30.0, 30.0), white, tr((0.0, 0.0, 0.0), radians(-90.0), ex))
+    lamp = d.sprite(d.geom("rectangle", 5.0, 5.0), d.mat("diffuse_light", d.tex_solid((5.0, 5.0, 5.0))), tr((0.0, 7.5, 1.0), radians(90.0), ex))
+    sky = d.sprite(d.geom("sphere", 60.0), d.mat("diffuse_light", d.tex_solid((0.3, 0.35, 0.45))), None)
+    d.world = [m1, m2, m3, m4, floor, lamp, sky]
+    d.camera = ((0.0, 2.6, -9.0), (0.0, 1.7, 1.0), (0.0, 1.0, 0.0), radians(42.0), float(aspect), 10.0, 0.0)
+    return d

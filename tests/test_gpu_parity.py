@@ -338,6 +338,17 @@ def test_deep_transform_chains_match_oracle(rt, scenes, oracle, gpu_device):
     _close(img, oracle.build_oracle(d).render(100, 80, 16, 40, seed=3, iterative=True, nthreads=8), max_bad=4)
 
 
+def test_media_inside_the_boundary_of_media_match_oracle(rt, scenes, oracle, gpu_device):
+    """ConstantMedium<T: Hit> with a ConstantMedium inside T, up to three levels (RT_FEAT_MEDIUM_NESTED): the general-media kernel
+    family evaluates the inner media per boundary.hit call with draws keyed by the outer evaluation"""
+    d = scenes.nested_media(1.25, seed=1)
+    sc, cam = scenes.build_product(d, device=gpu_device)
+    assert sc.info()["feature_mask"] & rt.RT_FEAT_MEDIUM_NESTED
+    img = sc.render(cam, 100, 80, 16, 30, seed=3)
+    assert sc.last_launch_config()["kernel_features"] & 8
+    _close(img, oracle.build_oracle(d).render(100, 80, 16, 30, seed=3, iterative=True, nthreads=8), max_bad=6)
+
+
 def test_render_sharded_over_scene_clones(rt, scenes, gpu_device):
     """rt_scene_clone + rt_render_sharded: the drivers' thread fan-out (examples/book-one.rs:52-88) inside the library --
     one host thread per committed copy, tiles dealt tile_id % n; clones wrap around on this one-GPU box"""

@@ -66,9 +66,15 @@ def test_error_conventions(rt):
         s.sprite(5, None)  # unknown geometry
     r = s.rectangle(1, 1)
     m = s.constant_medium(r, 0.1)  # ConstantMedium<T: Hit>: any boundary (src/volume.rs:40-43) ...
+    m2 = s.constant_medium(m, 0.1)  # ... a medium included (round 3), three levels deep
+    m3 = s.constant_medium(m2, 0.1)
+    deep = rt.Scene()
+    g4 = deep.constant_medium(deep.constant_medium(deep.constant_medium(deep.constant_medium(deep.sphere(1.0), 1.0), 1.0), 1.0), 1.0)
+    deep.sprite(g4, None)
     with pytest.raises(rt.RtError) as e:
-        s.constant_medium(m, 0.1)  # ... but a medium
-    assert e.value.code == -4
+        deep.commit(-1)  # four ConstantMedium levels inside one another: outside RT_MAX_MEDIUM_NESTING, an error at commit
+    assert e.value.code == -4 and "ConstantMedium levels" in str(e.value)
+    assert m3 > m2 > m
     with pytest.raises(rt.RtError) as e:
         s.bvh([])  # BoundingVolumeHierarchyNode::new(vec![]) -> None
     assert e.value.code == -2

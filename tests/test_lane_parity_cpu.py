@@ -312,3 +312,20 @@ def test_sixteen_levels_are_still_an_error(scenes, rt):
     with pytest.raises(rt.RtError) as e:
         scenes.build_product(d, device=-1)
     assert e.value.code == rt.ERR_UNSUPPORTED and "15" in str(e.value)
+
+
+def test_media_inside_the_boundary_of_media_exact(scenes, oracle, lane_emul, rt):
+    """ConstantMedium<T: Hit> with a ConstantMedium inside T (src/volume.rs:18-44; round 2 returned RT_ERR_UNSUPPORTED): a
+    medium over a medium over a sphere, a node of {sphere, medium over a cube} as a boundary (twice, under two media), three
+    levels behind a TransformedGeometry with a textured Isotropic.  Every inner evaluation draws a number keyed by the outer
+    evaluation's key and pass (include/rt_rng.h): flattened boundary prims against the oracle's recursive walk, bit for bit."""
+    d = scenes.nested_media(1.25, seed=1)
+    img, ref, cnt, ocnt, high, sc = both(scenes, oracle, lane_emul, d, 60, 48, 8, 30)
+    assert sc.info()["feature_mask"] & rt.RT_FEAT_MEDIUM_NESTED
+    assert np.array_equal(img, ref)
+    assert cnt["segments"] == ocnt["segments"]
+    assert img.std() > 0.05
+    for kw in ({"bvh_seed": 31}, {"world": "list"}):  # the oracle's tree / world form does not matter (keyed draws)
+        assert np.array_equal(img, oracle.build_oracle(d, **kw).render(60, 48, 8, 30, 1, iterative=True, nthreads=8))
+    img2, ref2, *_ = both(scenes, oracle, lane_emul, scenes.nested_media(1.0, seed=4), 40, 40, 4, 30, seed=11)
+    assert np.array_equal(img2, ref2)

@@ -431,3 +431,25 @@ def test_dielectric_and_mirror_furnace(oracle, scenes):
         centre = img[4, 4]
         assert np.all(centre >= expect_lo - 1e-12) and np.all(centre <= expect_hi + 1e-12), (mat, centre)
         assert np.array_equal(img[0, 0], [1.0, 1.0, 1.0])  # corner pixel sees the light directly
+
+
+def test_the_parity_anchor_has_no_hypothesis_branches(oracle):
+    """the ORC_HYP_* probes (earlier forms of ConstantMedium / Dielectric / Isotropic tried against cover.png)
+    live in a second, probe-only library; librt_oracle.so -- what every parity test and the CPU baseline run -- is the plain
+    restatement: it neither exports the switches nor contains the branches."""
+    import subprocess
+    from pathlib import Path
+    lib = Path(__file__).resolve().parent.parent / "oracle" / "_build" / "librt_oracle.so"
+    assert not hasattr(oracle.LIB, "orc_set_hypothesis")
+    syms = subprocess.run(["nm", "-D", "--defined-only", str(lib)], capture_output=True, text=True).stdout
+    assert "orc_render" in syms and "hypothesis" not in syms
+    src = (lib.parent.parent / "rt_oracle.cpp").read_text()
+    outside, depth = [], 0
+    for line in src.split("\n"):  # every use of the switches sits between #ifdef ORC_WITH_HYPOTHESES and its #endif
+        if line.startswith("#ifdef ORC_WITH_HYPOTHESES"):
+            depth += 1
+        elif line.startswith("#endif") and depth:
+            depth -= 1
+        elif depth == 0 and ("hypothesis" in line or "ORC_HYP_" in line):
+            outside.append(line)
+    assert not outside, outside

@@ -14,6 +14,10 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
+import os  # noqa: E402
+import subprocess  # noqa: E402
+subprocess.run(["make", "-C", str(ROOT / "oracle"), "hyp"], check=True, capture_output=True)
+os.environ["ORC_LIB"] = str(ROOT / "oracle" / "_build" / "librt_oracle_hyp.so")  # the probe-only library
 from __graft_entry__ import load_package  # noqa: E402
 
 load_package()
