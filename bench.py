@@ -68,9 +68,21 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(desc, name, W, H, spp_full, depth, seed, target_s):
-    """The oracle in reference form (recursive unpruned BVH, 4x4 per sprite, uv on every hit),
-    threaded like the example drivers, on a bounded sample of the same workload."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline(desc, name, W, H, spp_full, depth, seed, target_s, scenes=None):
+    """The oracle in reference form (recursive unpruned BVH, 4x4 per sprite, uv on every hit), threaded like the example
+    drivers, on a bounded sample of the same workload; plus (book-one) BASELINE configs[0] -- 400x225, 50 spp, depth 50, the
+    reference's own CPU-runnable case -- in full."""
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_binding
     o = oracle_binding.build_oracle(desc)
@@ -82,16 +94,26 @@ def cpu_baseline(desc, name, W, H, spp_full, depth, seed, target_s):
     t0 = time.perf_counter()
     o.render(W, H, spp, depth, seed, nthreads=cores)
     dt = time.perf_counter() - t0
-    return {"value": W * H * spp / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"{name} {W}x{H} at {spp} spp (of {spp_full}), depth {depth}, whole image, {dt:.1f} s; "
-                      f"oracle reference form, {cores} threads dealt rows y % n like examples/book-one.rs:56-65"}
+    out = {"value": W * H * spp / dt / 1e6, "unit": "Msamples/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
+           "sample": f"{name} {W}x{H} at {spp} spp (of {spp_full}), depth {depth}, whole image, {dt:.1f} s; "
+                     f"oracle reference form, {cores} threads dealt rows y % n like examples/book-one.rs:56-65"}
+    if scenes is not None and desc.name == "book-one":
+        w0, h0, s0, d0 = 400, 225, 50, 50
+        o0 = oracle_binding.build_oracle(scenes.book_one(1, w0 / h0))
+        t0 = time.perf_counter()
+        o0.render(w0, h0, s0, d0, seed, nthreads=cores)
+        dt0 = time.perf_counter() - t0
+        out["configs0_full"] = {"value": w0 * h0 * s0 / dt0 / 1e6, "unit": "Msamples/s", "seconds": dt0,
+                                "workload": f"book-one random-spheres {w0}x{h0}, {s0} spp, depth {d0} (BASELINE.json configs[0]), the whole render"}
+    return out
 
 
 def issue_roofline(rt, scene, W, H, spp, depth, world, kernel_ms, lane_util):
     """VALU-issue roofline of render_kernel from the committed rocprofv3 summary of this workload, if it belongs to this build."""
     out = {"bound": "valu_issue", "achieved": None, "peak": N_SIMD * MAX_CLOCK_GHZ, "unit": "Gcycle/s (VALU issue cycles, all 1024 SIMDs)",
            "frac": None, "useful_frac": None, "traffic": None, "source": None}
-    prof = ROOT / "profiles" / f"r02_{scene}" / "summary.json"
+    prof = next((p for p in (ROOT / "profiles" / f"r03_{scene}" / "summary.json", ROOT / "profiles" / f"r02_{scene}" / "summary.json") if p.exists()),
+                ROOT / "profiles" / f"r03_{scene}" / "summary.json")
     if world != 1:
         out["reason"] = "instruction counts are profiled on the whole image (N = 1) only"
         return out
@@ -103,8 +125,10 @@ def issue_roofline(rt, scene, W, H, spp, depth, world, kernel_ms, lane_util):
     if want not in s.get("command", "") or depth != 100:
         out["reason"] = f"{prof.relative_to(ROOT)} was taken on another workload ({s.get('command')})"
         return out
-    if s.get("library") != rt.version():
-        out["reason"] = f"{prof.relative_to(ROOT)} was taken with another build ({s.get('library')}) than the loaded {rt.version()}"
+    # the profile belongs to this build when the DEVICE code is the same (kernel hash of rt_version); host-side changes do not matter
+    prof_kernels = s["library"].split("kernels ", 1)[1].split(" ", 1)[0] if "kernels " in (s.get("library") or "") else None
+    if s.get("library") != rt.version() and prof_kernels != rt.kernel_hash():
+        out["reason"] = f"{prof.relative_to(ROOT)} was taken with other kernels ({s.get('library')}) than the loaded {rt.version()}"
         return out
     v = s.get("valu_issue_roofline")
     if not v:
@@ -112,8 +136,25 @@ def issue_roofline(rt, scene, W, H, spp, depth, world, kernel_ms, lane_util):
         return out
     issue = v["issue_cycles_total"]                      # issue cycles per launch (class counts x measured prices)
     achieved = issue / (kernel_ms * 1e-3) / 1e9          # with the kernel duration measured live in this run
+    per_s = 1.0 / (kernel_ms * 1e-3) / 1e9 / out["peak"]  # issue cycles per launch -> fraction of the chip's issue slots
+    ic = v["issue_cycles_per_launch"]
+    n_other = v["wave_instructions_per_launch"]["other"]
+    rest = issue - ic["other"]
     pmc_util = s.get("valu_lane_utilisation")  # SQ_THREAD_CYCLES_VALU / 64 / SQ_ACTIVE_INST_VALU of the profiled launch: every VALU instruction
+    pm = s.get("pmc") or {}
+    busy = (pm.get("SQ_ACTIVE_INST_VALU") or {}).get("mean_per_dispatch")
     out.update({"achieved": achieved, "frac": achieved / out["peak"], "useful_frac": achieved / out["peak"] * (pmc_util or lane_util),
+                # the hardware exposes no counter for moves / selects / compares / lane operations (the SQ_INSTS_VALU_* classes are
+                # ADD / MUL / FMA / TRANS per type, INT32, INT64, CVT), so the unclassified half of the instructions is priced by a
+                # static mix; the envelope prices it at the cheapest (2) and the dearest (4 cycles) such instruction instead
+                "frac_envelope_other_at_2_and_4_cycles": [(rest + 2.0 * n_other) * per_s, (rest + 4.0 * n_other) * per_s],
+                # binary64 arithmetic alone (ADD / MUL / FMA / TRANS f64 issue cycles over the chip's issue slots): the part of
+                # `frac` that is the reference's own arithmetic; it rises when bookkeeping instructions are removed
+                "f64_math_frac": (ic["f64"] + ic["trans_f64"]) * per_s,
+                # the hardware's own word: quad-cycles a SIMD had a VALU instruction in flight x 4 / (1024 SIMDs x elapsed cycles) of
+                # the profiled launch.  It bounds: ~1 means no VALU cycle is left, whatever the instruction prices say; the gap to
+                # `frac` is what the nominal prices do not see (dependent-issue stalls, 4.2- instead of 4-cycle forms)
+                "valu_busy_frac_pmc": (busy * 4.0 / (N_SIMD * v["elapsed_shader_cycles"])) if busy and v.get("elapsed_shader_cycles") else None,
                 "useful_frac_vote_blocks_only": achieved / out["peak"] * lane_util,
                 "traffic": (s.get("hbm_traffic_bytes_per_launch") or {}).get("total"),
                 "source": f"{prof.relative_to(ROOT)} (rocprofv3 --pmc passes of `{s['command']}`, build {rt.build_hash()}); "
@@ -359,7 +400,7 @@ def main():
             last = host_images[(step_no[0] - 1) & 1]
             res["image_matches_single_gpu"] = bool(np.array_equal(last.numpy().reshape(H, W, 3), whole))
         if not a.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(desc, scene_words, W, H, spp, depth, a.seed, a.cpu_seconds)
+            res["cpu_baseline"] = cpu_baseline(desc, scene_words, W, H, spp, depth, a.seed, a.cpu_seconds, scenes)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))

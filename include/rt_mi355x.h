@@ -168,9 +168,6 @@ typedef struct rt_counters {
     /* lanes that sat idle while the node block ran, by what they were waiting for: a finished segment waiting for the shade
      * quorum, a leaf waiting for the leaf quorum, no path at all */
     uint64_t node_idle_done, node_idle_leaf, node_idle_empty;
-    /* ray exchange (kernels with the ray queue): executions of the exchange block, hits parked and rays pulled by it, rays
-     * a shading wave pushed for others */
-    uint64_t xchg_wave, xchg_parked, xchg_pulled, xchg_pushed;
 } rt_counters;
 
 /* Render into host memory: out_rgb[(y*W + x)*3 + c].  With shard_count > 1 only

@@ -54,8 +54,7 @@ class rt_counters(C.Structure):
                                             "node_cycles", "leaf_cycles", "shade_cycles", "finish_cycles", "refill_cycles",
                                             "begin_cycles", "swap_class_mode", "swap_new_mode", "swap_parked", "swap_pulled",
                                             "swap_lock_busy", "swap_scattered", "swap_off_class", "swap_cycles",
-                                            "node_idle_done", "node_idle_leaf", "node_idle_empty",
-                                            "xchg_wave", "xchg_parked", "xchg_pulled", "xchg_pushed")]
+                                            "node_idle_done", "node_idle_leaf", "node_idle_empty")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -456,6 +455,12 @@ def version() -> str:
 def build_hash() -> str:
     """source hash the loaded library was built from (rt_version)"""
     return version().rsplit("src ", 1)[-1]
+
+
+def kernel_hash() -> str:
+    """hash of the device sources alone (rt_version): profiles of the kernels stay valid across host-side changes"""
+    v = version()
+    return v.split("kernels ", 1)[1].split(" ", 1)[0] if "kernels " in v else build_hash()
 
 
 def source_hash() -> str:

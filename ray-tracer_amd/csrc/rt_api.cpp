@@ -85,7 +85,10 @@ const char *rt_last_error(void) { return g_err.c_str(); }
 #ifndef RT_SOURCE_HASH
 #define RT_SOURCE_HASH "unknown"
 #endif
-const char *rt_version(void) { return "rt_mi355x 0.2 (gfx950, f64) src " RT_SOURCE_HASH; }
+#ifndef RT_KERNEL_HASH
+#define RT_KERNEL_HASH "unknown"
+#endif
+const char *rt_version(void) { return "rt_mi355x 0.3 (gfx950, f64) kernels " RT_KERNEL_HASH " src " RT_SOURCE_HASH; }
 
 int rt_device_count(void) {
     int n = 0;
@@ -337,6 +340,7 @@ static unsigned kernel_features(const rt_scene *s) {
     if (s->flat.feature_mask & RT_FEAT_TEXTURED) f |= 4u;
     if (s->flat.feature_mask & (RT_FEAT_MEDIUM_GENERAL | RT_FEAT_DEEP_CHAIN)) f |= 8u; // + 2: that family is compiled with media
     if (s->flat.feature_mask & RT_FEAT_DEEP_CHAIN) f |= 2u | 4u;
+    if (s->flat.feature_mask & RT_FEAT_MEDIUM_NESTED) f |= 16u | 8u | 4u | 2u | 1u; // the family with the nested evaluation (MEDIUM = 3)
     if (s->flat.wide) f |= 1u; // 32-bit references exist in the general kernel families only
     return f;
 }
@@ -436,18 +440,19 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     const char *no_lds = std::getenv("RT_NO_LDS_NODES");
     // RT_SWAP=0 selects the kernels without the queues (A/B runs)
     const char *swap_env = std::getenv("RT_SWAP");
-    const int swap = !(swap_env && *swap_env == '0');
+    const int swap = !(swap_env && *swap_env == '0') || (feat & 16u) != 0u; // (the nested-media family exists with the queues only)
     // keep the kernel family's full occupancy resident: that many workgroups per CU share its LDS
     const unsigned groups_per_cu = std::max(1u, (unsigned)rt_kernel_waves_per_simd(feat) * 256u / block);
     const unsigned lds_share = (RT_LDS_PER_CU / groups_per_cu) & ~(RT_LDS_GRANULE - 1u);
     const int list = s->flat.n_list > 0; // the box list (< 1 KB) always lives in LDS
     const unsigned min_cap = swap ? (block >= 512u ? (unsigned)RT_SWAP_CAP : 32u) : 0u; // the node copy must leave room for this
+    const unsigned n_queues = rt_swap_queues(feat != 0u); // the general families keep a ray queue besides the three class queues
     const int ldsnodes = list || (!wide && node_bytes > 0 && !(no_lds && *no_lds == '1') &&
-                                  rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, node_bytes, min_cap).total <= lds_share);
+                                  rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, node_bytes, min_cap, n_queues).total <= lds_share);
     const unsigned in_lds = ldsnodes ? node_bytes : 0u;
-    const unsigned swap_cap = swap ? rt_swap_cap_that_fits((unsigned)L.stack_entries, block, entry_bytes, in_lds, groups_per_cu) : 0u;
+    const unsigned swap_cap = swap ? rt_swap_cap_that_fits((unsigned)L.stack_entries, block, entry_bytes, in_lds, groups_per_cu, n_queues) : 0u;
     L.swap_cap = (int)swap_cap;
-    const RtLdsLayout lay = rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, in_lds, swap ? rt_swap_cap_effective(block, swap_cap) : 0u);
+    const RtLdsLayout lay = rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, in_lds, swap ? rt_swap_cap_effective(block, swap_cap) : 0u, n_queues);
     if (!rt_lds_layout_aligned(lay)) return fail(RT_ERR_DEVICE, "internal: misaligned LDS layout");
     const unsigned lds_bytes = lay.total;
     if (lds_bytes > RT_LDS_PER_CU) return fail(RT_ERR_UNSUPPORTED, "the scene's traversal stack does not fit a CU's LDS");
@@ -456,7 +461,7 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
         if (*t == '1') L.lds_bytes = lds_bytes - 64u;
     const int lds_mode = (ldsnodes ? 1 : 0) | (swap ? 2 : 0) | (wide ? 4 : 0) | (list ? 8 : 0);
     int per_cu = 0, n_cu = 0, rc = 0;
-    const unsigned occ_key = feat | (lens ? 16u : 0u) | (count ? 32u : 0u) | ((unsigned)lds_mode << 6); // feat uses bits 0-3
+    const unsigned occ_key = feat | (lens ? 32u : 0u) | (count ? 64u : 0u) | ((unsigned)lds_mode << 7); // feat uses bits 0-4
     if (s->occ_key == occ_key && s->occ_lds == lds_bytes) {
         per_cu = s->occ_per_cu;
         n_cu = s->occ_n_cu;
@@ -726,10 +731,6 @@ int rt_render(rt_scene *s, const rt_camera *cam, const rt_render_params *p, doub
             counters->node_idle_done = c.node_idle_done;
             counters->node_idle_leaf = c.node_idle_leaf;
             counters->node_idle_empty = c.node_idle_empty;
-            counters->xchg_wave = c.xchg_wave;
-            counters->xchg_parked = c.xchg_parked;
-            counters->xchg_pulled = c.xchg_pulled;
-            counters->xchg_pushed = c.xchg_pushed;
         }
     }
     (void)hipFree(d_out);

@@ -879,7 +879,9 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
     // the device gets the box list in the node array's place.  RT_NO_LIST=1 keeps the tree walk (A/B runs).
     const int n_bvh_leaves = fs.n_leaf_prims - fs.n_hoisted;
     const char *no_list = std::getenv("RT_NO_LIST");
-    if ((fs.feature_mask & RT_FEAT_GENERAL) && !fs.wide && n_bvh_leaves >= 2 && n_bvh_leaves <= RT_LIST_MAX && !(no_list && *no_list == '1')) {
+    // (a scene with media inside media is always walked as a tree: its kernel family is compiled in that form only)
+    if ((fs.feature_mask & RT_FEAT_GENERAL) && !(fs.feature_mask & RT_FEAT_MEDIUM_NESTED) && !fs.wide && n_bvh_leaves >= 2 && n_bvh_leaves <= RT_LIST_MAX &&
+        !(no_list && *no_list == '1')) {
         fs.n_list = n_bvh_leaves;
         std::vector<float> packed((size_t)n_bvh_leaves * RT_LIST_BOX_FLOATS, 0.0f);
         for (int i = 0; i < n_bvh_leaves; ++i) {

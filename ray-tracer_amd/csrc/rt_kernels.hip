@@ -770,7 +770,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
     }
 }
 
-#if RT_TU_PART != 2
+#if RT_TU_PART == 0 || RT_TU_PART == 1
 // Sum this pass's samples in sample order on top of the running sums; the last
 // pass divides by spp (`pixel /= subPixelSampleCount`, examples/book-one.rs:76).
 // One thread per owned pixel; consecutive threads read consecutive 32-byte records.
@@ -834,7 +834,7 @@ __global__ void probe_math_kernel(const double *a, const double *b, int n, doubl
     out_div[i] = a[i] / b[i];
 }
 
-#endif // RT_TU_PART != 2
+#endif // parts 0 / 1
 
 // ---- dispatch over the template instantiations ----
 typedef void (*KernelFn)(const RtLaunch);
@@ -859,7 +859,17 @@ KernelFn pick3(bool lens, bool count, bool ldsnodes) {
 }
 // lds_mode: bit 0 = node array copied to LDS, bit 1 = swap-at-shade queues, bit 2 = 32-bit references (general families),
 // bit 3 = box list instead of the tree (general families, 16-bit references, always in LDS)
-#if RT_TU_PART != 1
+#if RT_TU_PART == 0 || RT_TU_PART == 3
+// media inside the boundary of media (feature bit 16): MEDIUM = 3, the only family compiled with the nested evaluation (a real
+// call per inner medium, records in scratch memory: 6 x slower than MEDIUM = 2 on the same scene, so it is kept out of it).
+// Tree walk only, always with the swap queues.
+KernelFn pick_nested(bool lens, bool count, int lds_mode) {
+    const bool ldsnodes = (lds_mode & 1) != 0, wide = (lds_mode & 4) != 0;
+    if (wide) return pick3<true, 3, true, true, true>(lens, count, false);
+    return pick3<true, 3, true, true>(lens, count, ldsnodes);
+}
+#endif
+#if RT_TU_PART == 0 || RT_TU_PART == 2
 // the families with media / textures (feature bits 2, 4, 8)
 KernelFn pick_media(unsigned features, bool lens, bool count, int lds_mode) {
     const bool ldsnodes = (lds_mode & 1) != 0, swap = (lds_mode & 2) != 0, wide = (lds_mode & 4) != 0, list = (lds_mode & 8) != 0;
@@ -881,13 +891,23 @@ KernelFn pick_media(unsigned features, bool lens, bool count, int lds_mode) {
 extern "C" void *rt_pick_media_kernel(unsigned features, int lens, int count, int lds_mode) {
     return (void *)pick_media(features, lens != 0, count != 0, lds_mode);
 }
+#elif RT_TU_PART == 3
+extern "C" void *rt_pick_nested_kernel(int lens, int count, int lds_mode) { return (void *)pick_nested(lens != 0, count != 0, lds_mode); }
 #elif RT_TU_PART == 1
 extern "C" void *rt_pick_media_kernel(unsigned features, int lens, int count, int lds_mode);
+extern "C" void *rt_pick_nested_kernel(int lens, int count, int lds_mode);
 #endif
-#if RT_TU_PART != 2
+#if RT_TU_PART == 0 || RT_TU_PART == 1
 namespace {
 KernelFn pick(unsigned features, bool lens, bool count, int lds_mode) {
     const bool ldsnodes = (lds_mode & 1) != 0, swap = (lds_mode & 2) != 0, wide = (lds_mode & 4) != 0, list = (lds_mode & 8) != 0;
+    if (features & 16u) {
+#if RT_TU_PART == 1
+        return (KernelFn)rt_pick_nested_kernel(lens, count, lds_mode);
+#else
+        return pick_nested(lens, count, lds_mode);
+#endif
+    }
     if ((features & ~1u) != 0u) {
 #if RT_TU_PART == 1
         return (KernelFn)rt_pick_media_kernel(features, lens, count, lds_mode);
@@ -970,4 +990,4 @@ extern "C" int rt_launch_probe_math(const double *a, const double *b, int n, dou
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
-#endif // RT_TU_PART != 2
+#endif // parts 0 / 1

@@ -592,7 +592,7 @@ RT_HD bool medium_general_hit(const RtLaunch &L, const RtPrimGeo &G, V3 o, V3 d,
 // Intersect primitive `pi` with the world ray; on a hit fill the world-space record.
 // RECORD = false: only r->t is meaningful (traversal); true: full record (shading), uv when `uv`.
 // MEDIUM: 0 no media in the scene, 1 only ConstantMedium<Sphere> sprites under a pure translation (RT_PRIM_MEDIUM_T,
-// the reference's own scenes), 2 media over any boundary (RT_PRIM_MEDIUM_C) as well.
+// the reference's own scenes), 2 media over any boundary (RT_PRIM_MEDIUM_C) as well, 3 media inside the boundary of media too.
 template <bool GENERAL, int MEDIUM, bool RECORD>
 RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx &sc, Rec *r, bool uv_wanted) {
     // uv inside the record is only ever asked for by prim_uv's medium case (kernel family MEDIUM = 2)
@@ -630,7 +630,7 @@ RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx
         chain_down<(MEDIUM >= 2)>(L, first, len, tmask, &lo, &ld);
         bool ok;
         if (MEDIUM >= 2 && kind == RT_PRIM_MEDIUM_C)
-            ok = medium_general_hit<RT_MAX_MEDIUM_NESTING - 1>(L, G, lo, ld, sc.rng_base, sc.segment, P.aux, &sc.draws, &sc.prims_tested, uv, r);
+            ok = medium_general_hit<(MEDIUM >= 3 ? RT_MAX_MEDIUM_NESTING - 1 : 0)>(L, G, lo, ld, sc.rng_base, sc.segment, P.aux, &sc.draws, &sc.prims_tested, uv, r);
         else
             ok = shape_hit<RECORD>(kind, G, lo, ld, uv, r);
         if (!ok) return false;
@@ -749,9 +749,8 @@ RT_HD void trav_pop(Trav &tv, Stack &st) {
     }
 }
 
-// start a segment: binary32 ray constants, hoisted prims, root
-template <bool GENERAL, int MEDIUM, class Stack>
-RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack &st) {
+// binary32 constants of a segment's ray (what a traversal needs besides o, d and the best hit so far)
+RT_HD void trav_ray_constants(const RtLaunch &L, V3 o, V3 d, Trav &tv) {
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
     tv.idx = rcp32((float)d.x);
     tv.idy = rcp32((float)d.y);
@@ -773,6 +772,12 @@ RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack
     tv.ox = (f32_bits(tv.idx) >> 31) * flip;
     tv.oy = (f32_bits(tv.idy) >> 31) * flip + ay;
     tv.oz = (f32_bits(tv.idz) >> 31) * flip + az;
+}
+
+// start a segment: binary32 ray constants, hoisted prims, root
+template <bool GENERAL, int MEDIUM, class Stack>
+RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack &st) {
+    trav_ray_constants(L, o, d, tv);
     tv.best_t = RTL_INF;
     tv.best_prim = 0xFFFFFFFFu;
     const double a = dot(d, d);
@@ -787,6 +792,16 @@ RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack
             }
         }
     }
+    tv.best32 = up32(tv.best_t);
+    tv.sp = 0;
+    tv.cur = L.root;
+}
+
+// take over a segment that another lane began (the ray exchange of rt_kernels.hip): o, d and the result of the hoisted
+// tests (best_t, best_prim) travelled; everything else of the traversal state is a function of those
+RT_HD void trav_resume(const RtLaunch &L, V3 o, V3 d, Trav &tv) {
+    trav_ray_constants(L, o, d, tv);
+    tv.r2a = world_roots_rcp(L, o, dot(d, d));
     tv.best32 = up32(tv.best_t);
     tv.sp = 0;
     tv.cur = L.root;

@@ -135,7 +135,6 @@ struct RtCounters {
     // swap-at-shade diagnostics (see include/rt_mi355x.h)
     unsigned long long swap_class_mode, swap_new_mode, swap_parked, swap_pulled, swap_lock_busy, swap_scattered, swap_off_class, swap_cycles;
     unsigned long long node_idle_done, node_idle_leaf, node_idle_empty;
-    unsigned long long xchg_wave, xchg_parked, xchg_pulled, xchg_pushed;
 };
 
 // kernel arguments (passed by value)

@@ -8,6 +8,7 @@
 #include "../../../include/rt_rng.h"
 
 #include <cstdio>
+#include <unistd.h>
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
@@ -169,10 +170,20 @@ inline int run(const Options &o, const std::vector<SpritePtr> &sprites, const Pe
         // checkpoint = header + raw sums.  The header names the render AND the scene (a resume with another --scene-seed, or
         // another driver at the same size, must not add samples of a different picture); the file is replaced atomically
         // (tmp + rename) and a file that does not match or is damaged is refused, never overwritten.
+        // ... and the library's DEVICE code (the "kernels <hash>" token of rt_version: sample streams, keying and arithmetic live
+        // there): sums made by other kernels are never continued.
         struct Header {
-            uint64_t magic, version, width, height, spp, depth, seed, scene_seed, scene_hash, camera_hash, s_done;
-        } h{0x3250545252ull, 2, (uint64_t)o.width, (uint64_t)o.height, (uint64_t)o.spp, (uint64_t)o.depth, o.seed, o.scene_seed,
-            world->hash(), 0, 0};
+            uint64_t magic, version, width, height, spp, depth, seed, scene_seed, scene_hash, camera_hash, kernels_hash, s_done;
+        } h{0x3250545252ull, 3, (uint64_t)o.width, (uint64_t)o.height, (uint64_t)o.spp, (uint64_t)o.depth, o.seed, o.scene_seed,
+            world->hash(), 0, 0, 0};
+        {
+            const std::string v = rt_version();
+            const size_t at = v.find("kernels ");
+            const std::string token = at == std::string::npos ? v : v.substr(at, v.find(' ', at + 8) - at);
+            uint64_t kh = 0xcbf29ce484222325ull;
+            for (unsigned char c : token) kh = (kh ^ c) * 0x100000001b3ull;
+            h.kernels_hash = kh;
+        }
         {
             uint64_t ch = 0xcbf29ce484222325ull;
             const unsigned char *cb = (const unsigned char *)&camera.c;
@@ -187,11 +198,12 @@ inline int run(const Options &o, const std::vector<SpritePtr> &sprites, const Pe
                 const bool header_ok = std::fread(&g, sizeof g, 1, f) == 1;
                 const bool same = header_ok && g.magic == h.magic && g.version == h.version && g.width == h.width && g.height == h.height &&
                                   g.spp == h.spp && g.depth == h.depth && g.seed == h.seed && g.scene_seed == h.scene_seed &&
-                                  g.scene_hash == h.scene_hash && g.camera_hash == h.camera_hash && g.s_done <= h.spp;
+                                  g.scene_hash == h.scene_hash && g.camera_hash == h.camera_hash && g.kernels_hash == h.kernels_hash &&
+                                  g.s_done <= h.spp;
                 const bool whole = same && std::fread(sums.data(), sizeof(double), sums.size(), f) == sums.size();
                 std::fclose(f);
                 if (!same) {
-                    std::fprintf(stderr, "checkpoint %s belongs to another render (size, spp, depth, seed, scene or camera differ) -- "
+                    std::fprintf(stderr, "checkpoint %s belongs to another render (size, spp, depth, seed, scene, camera or the library's kernels differ) -- "
                                          "not touching it; remove it or pass another --checkpoint\n", o.checkpoint.c_str());
                     return 3;
                 }
@@ -218,6 +230,7 @@ inline int run(const Options &o, const std::vector<SpritePtr> &sprites, const Pe
                 ok = ok && std::fwrite(&h, sizeof h, 1, f) == 1;
                 ok = ok && std::fwrite(sums.data(), sizeof(double), sums.size(), f) == sums.size();
                 ok = ok && std::fflush(f) == 0;
+                ok = ok && ::fsync(::fileno(f)) == 0; // on the disk BEFORE it takes the old file's name: a power loss leaves one whole file
                 if (f) ok = (std::fclose(f) == 0) && ok;
                 ok = ok && std::rename(tmp.c_str(), o.checkpoint.c_str()) == 0;
                 if (!ok) {

@@ -62,10 +62,6 @@ pub struct rt_counters {
     pub node_idle_done: u64,
     pub node_idle_leaf: u64,
     pub node_idle_empty: u64,
-    pub xchg_wave: u64,
-    pub xchg_parked: u64,
-    pub xchg_pulled: u64,
-    pub xchg_pushed: u64,
 }
 
 #[repr(C)]

@@ -131,14 +131,14 @@ extern "C" int lane_emul_render(rt_scene *s, const rt_camera *cam, int W, int H,
             run<false, 0, false, false>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
     } else if (!s->flat.wide) {
         if (lens)
-            run<true, 2, true, true>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
+            run<true, 3, true, true>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
         else
-            run<true, 2, true, false>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
+            run<true, 3, true, false>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
     } else {
         if (lens)
-            run<true, 2, true, true, RtRef32>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
+            run<true, 3, true, true, RtRef32>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
         else
-            run<true, 2, true, false, RtRef32>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
+            run<true, 3, true, false, RtRef32>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
     }
     if (counters) std::memcpy(counters, cnt, sizeof cnt);
     if (stack_high) *stack_high = hw;
@@ -192,10 +192,10 @@ extern "C" void lane_emul_medium_forms(const double oc[3], const double d[3], do
 // the shared LDS layout (ray-tracer_amd/csrc/rt_lds.h) for host-side sweeps: out = {stack_off, node_off, job_off, swap_off,
 // swap_class_bytes, total, aligned, cap that fits, effective cap}
 extern "C" void lane_emul_lds_layout(unsigned stack_entries, unsigned block, unsigned entry_bytes, unsigned node_bytes, unsigned groups_per_cu,
-                                     unsigned *out) {
-    const uint32_t cap = rt_swap_cap_that_fits(stack_entries, block, entry_bytes, node_bytes, groups_per_cu);
+                                     unsigned n_queues, unsigned *out) {
+    const uint32_t cap = rt_swap_cap_that_fits(stack_entries, block, entry_bytes, node_bytes, groups_per_cu, n_queues);
     const uint32_t eff = rt_swap_cap_effective(block, cap);
-    const RtLdsLayout l = rt_lds_layout(stack_entries, block, entry_bytes, node_bytes, eff);
+    const RtLdsLayout l = rt_lds_layout(stack_entries, block, entry_bytes, node_bytes, eff, n_queues);
     out[0] = l.stack_off;
     out[1] = l.node_off;
     out[2] = l.job_off;

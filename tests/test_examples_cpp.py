@@ -116,8 +116,8 @@ def test_cpp_driver_progressive_and_resume(binaries, gpu_device, tmp_path):
     # truncate the checkpoint's progress to 4 spp worth of sums by re-running passes from a saved early state
     import struct
     raw = ck.read_bytes()
-    hdr = list(struct.unpack("<11Q", raw[:88]))
-    assert hdr[1:8] == [2, 64, 40, 12, 50, 9, 3] and hdr[10] == 12
+    hdr = list(struct.unpack("<12Q", raw[:96]))  # magic, version, w, h, spp, depth, seed, scene seed, scene / camera / kernels hash, s_done
+    assert hdr[1:8] == [3, 64, 40, 12, 50, 9, 3] and hdr[11] == 12
     # build a genuine 4-spp checkpoint with the API and let the driver resume it
     import importlib
     import numpy as np
@@ -128,8 +128,8 @@ def test_cpp_driver_progressive_and_resume(binaries, gpu_device, tmp_path):
     sums = np.zeros((40, 64, 3))
     sc.render_progressive(cam, 64, 40, 12, 50, 9, 0, 4, sums)
     assert hdr[8] == sc.scene_hash()  # the header names the scene the sums belong to
-    hdr[10] = 4
-    ck.write_bytes(struct.pack("<11Q", *hdr) + sums.tobytes())
+    hdr[11] = 4
+    ck.write_bytes(struct.pack("<12Q", *hdr) + sums.tobytes())
     res = tmp_path / "resumed.ppm"
     r = subprocess.run([str(binaries / "book_one"), *common, "--passes", "3", "--checkpoint", str(ck), "--out", str(res)],
                        check=True, capture_output=True, text=True)
@@ -146,6 +146,14 @@ def test_cpp_driver_progressive_and_resume(binaries, gpu_device, tmp_path):
     r = subprocess.run([str(binaries / "cornell_box"), *common, "--passes", "3", "--checkpoint", str(ck), "--out", str(res)],
                        capture_output=True, text=True)
     assert r.returncode == 3 and ck.read_bytes() == before
+    # ... and so are sums made by other kernels (header field 10 = hash of the library's device code, rt_version "kernels ...")
+    alien = list(hdr)
+    alien[10] ^= 1
+    ck.write_bytes(struct.pack("<12Q", *alien) + sums.tobytes())
+    r = subprocess.run([str(binaries / "book_one"), *common, "--passes", "3", "--checkpoint", str(ck), "--out", str(res)],
+                       capture_output=True, text=True)
+    assert r.returncode == 3 and "kernels" in r.stderr
+    ck.write_bytes(before)
     # a truncated file is refused as well (never silently restarted from zero)
     ck.write_bytes(before[:len(before) // 2])
     r = subprocess.run([str(binaries / "book_one"), *common, "--passes", "3", "--checkpoint", str(ck), "--out", str(res)],

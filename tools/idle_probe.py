@@ -22,7 +22,7 @@ for name, desc, W, H, spp in (("book_one", scenes.book_one(1, 1.5), 1200, 800, 3
     r = {"node_exec_per_sample": c["node_wave"] * 64 / c["samples"], "at_node": c["node_lane"] / nw / 64, "idle_leaf": c["node_idle_leaf"] / nw / 64,
          "idle_done": c["node_idle_done"] / nw / 64, "idle_empty": c["node_idle_empty"] / nw / 64,
          "leaf_occ": c["leaf_lane"] / max(1, c["leaf_wave"]) / 64, "shade_occ": c["shade_lane"] / max(1, c["shade_wave"]) / 64,
-         "xchg": {k: c[k] for k in c if k.startswith("xchg_")}, "launch": sc.last_launch_config()}
+         "launch": sc.last_launch_config()}
     out[name] = r
     print(name, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items() if k != "launch"}, flush=True)
     sc.close()
