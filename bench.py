@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--check", action="store_true", help="rank 0 also renders the whole image alone and compares (default for N > 1)")
     ap.add_argument("--no-check", action="store_true", help="skip that comparison for N > 1")
+    ap.add_argument("--no-defer", action="store_true",
+                    help="sum each step's sample records on the render stream instead of behind it (RT_FLAG_DEFERRED_OUTPUT off): "
+                         "reduce_kernel (HBM-bound) then no longer overlaps the next step's render_kernel (VALU-bound)")
     ap.add_argument("--pipeline", action="store_true",
                     help="experiment: consecutive steps on two alternating streams (measured slower, see DESIGN.md section 8)")
     return ap.parse_args()
@@ -249,7 +252,10 @@ def main():
     # --pipeline: two of everything a step writes and consecutive steps on alternating streams, so that the render of
     # step k+1 could fill the CUs while step k's last few 100-segment paths, its reduce, gather and unpack finish (the
     # library keeps two render slots per scene).  Measured SLOWER than one stream on the MI355X, so it is off by default
-    n_buf = 2 if a.pipeline else 1
+    # default (deferred output): ONE render stream -- render kernels never overlap each other -- and everything behind a render
+    # kernel (the sums of its sample records, gather, unpack, copy) on a second stream, overlapping the next step's render
+    defer = not a.no_defer and not a.pipeline
+    n_buf = 2 if (a.pipeline or defer) else 1
     mines = [torch.zeros(pad_tiles * 64 * 3, dtype=torch.float64, device=dev) for _ in range(n_buf)]
     gathereds = [torch.zeros(world * pad_tiles * 64 * 3, dtype=torch.float64, device=dev) if rank == 0 else None for _ in range(n_buf)]
     # default: the current stream, as ever; only the --pipeline experiment creates side streams
@@ -261,13 +267,15 @@ def main():
     host_images = [torch.zeros(H * W * 3, dtype=torch.float64).pin_memory() for _ in range(2)] if rank == 0 else None
     copy_stream = torch.cuda.Stream(device=dev) if rank == 0 else None
     copy_done = [torch.cuda.Event() for _ in range(2)] if rank == 0 else None
+    post_stream = torch.cuda.Stream(device=dev) if defer else None
+    post_done = [torch.cuda.Event() for _ in range(2)] if defer else None
     step_no = [0]
 
     def step(marks=None):
         """one render of the whole image; marks (optional) collects CUDA events after render / gather / unpack / copy"""
         k = step_no[0]
         step_no[0] += 1
-        rs = render_streams[k % n_buf]
+        rs = render_streams[k % len(render_streams)]
         mine_k, gathered_k = mines[k % n_buf], gathereds[k % n_buf]
 
         def mark(name, stream_obj):
@@ -276,11 +284,20 @@ def main():
                 e.record(stream_obj)
                 marks.append((name, e))
 
+        if defer:
+            rs.wait_event(post_done[k % 2])  # step k - 2 has finished reading mine_k / gathered_k
+            mark("start", rs)
+            sc.render_tiles_device(cam, W, H, spp, depth, a.seed, (rank, world), mine_k.data_ptr(), None, rs.cuda_stream,
+                                   flags=rt.RT_FLAG_DEFERRED_OUTPUT)
+            mark("render", rs)
+            sc.wait_output(post_stream.cuda_stream)  # the post stream waits for this step's sums
+            rs = post_stream
         with torch.cuda.stream(rs):
             stream = rs.cuda_stream
-            mark("start", rs)
-            sc.render_tiles_device(cam, W, H, spp, depth, a.seed, (rank, world), mine_k.data_ptr(), None, stream)
-            mark("render", rs)
+            if not defer:
+                mark("start", rs)
+                sc.render_tiles_device(cam, W, H, spp, depth, a.seed, (rank, world), mine_k.data_ptr(), None, stream)
+                mark("render", rs)
             if world > 1 and a.backend == "nccl":
                 glist = list(gathered_k.chunk(world)) if rank == 0 else None
                 dist.gather(mine_k, glist, dst=0)  # the one collective of the path (RCCL over xGMI)
@@ -304,6 +321,8 @@ def main():
                     host_images[b].copy_(images[b], non_blocking=True)
                     copy_done[b].record(copy_stream)
                     mark("d2h", copy_stream)
+            if defer:
+                post_done[k % 2].record(rs)
 
     def sync():
         if world > 1:
@@ -391,7 +410,8 @@ def main():
             "config": {"workload": f"{scene_words} {W}x{H}, {spp} spp, depth {depth}" + (f" (BASELINE.json {cfg_name})" if cfg_name else ""),
                        "scene_seed": a.scene_seed, "render_seed": a.seed, "n_prims": info["n_prims"],
                        "bvh_nodes": info["n_nodes"], "sharding": f"8x8 tiles, tile_id % {world}, one RCCL gather",
-                       "library": rt.version(), "steps_pipelined_on_two_streams": bool(a.pipeline)},
+                       "library": rt.version(), "steps_pipelined_on_two_streams": bool(a.pipeline),
+                       "sums_behind_the_next_render": bool(defer)},
             "roofline": roof, "wall_s": dt, "last_kernel_ms": last_kernel_ms,
             "step_anatomy_ms": per_rank if per_rank is not None else [dict(anatomy, rank=0, device=local_rank, tiles=n_tiles[0])],
         }

@@ -152,6 +152,7 @@ typedef struct rt_render_params {
 
 #define RT_TILE 8                 /* tile edge in pixels */
 #define RT_FLAG_COUNTERS 1u       /* also accumulate rt_counters (slower build of the kernel) */
+#define RT_FLAG_DEFERRED_OUTPUT 2u /* rt_render_tiles_device only: see rt_render_wait_output */
 
 typedef struct rt_counters {
     uint64_t samples, segments, nodes_visited, prims_tested, rng_draws;
@@ -204,6 +205,13 @@ int rt_render_progressive(rt_scene *, const rt_camera *, const rt_render_params 
 int rt_shard_tile_count(int width, int height, int shard_index, int shard_count);
 int rt_render_tiles_device(rt_scene *, const rt_camera *, const rt_render_params *, void *d_tiles_out, void *d_counters,
                            void *stream);
+/* Pipelining consecutive renders.  A render is two kernels: render_kernel (bound by the VALUs) and reduce_kernel, which sums the
+ * sample records in sample order (bound by HBM).  With RT_FLAG_DEFERRED_OUTPUT in params->flags rt_render_tiles_device enqueues
+ * only render_kernel on `stream`; reduce_kernel follows it on a stream of the scene's own, so the next render on `stream` starts
+ * while the sums of this one are still being read (each render uses its own workspace slot).  d_tiles_out is complete where
+ * rt_render_wait_output(scene, any_stream) -- called after that rt_render_tiles_device and before the next one on this scene --
+ * puts its wait.  Results are bit-identical; bench.py uses it (3.7 % of a step). */
+int rt_render_wait_output(rt_scene *, void *stream);
 /* Un-permute gathered shards into a row-major image on the device:
  * d_gathered = shard_count buffers of `tiles_per_shard_padded` tiles each,
  * back to back (what one RCCL gather of equal-sized chunks produces). */

@@ -26,6 +26,7 @@ LIB_PATH = Path(os.environ.get("RT_MI355X_LIB") or (_HERE / "lib" / "librt_mi355
 
 RT_TILE = 8
 RT_FLAG_COUNTERS = 1
+RT_FLAG_DEFERRED_OUTPUT = 2
 RT_FEAT_SPHERE_T, RT_FEAT_GENERAL, RT_FEAT_MEDIUM, RT_FEAT_TEXTURED, RT_FEAT_LENS, RT_FEAT_MEDIUM_GENERAL, RT_FEAT_WIDE = 1, 2, 4, 8, 16, 32, 64
 RT_FEAT_DEEP_CHAIN = FEAT_DEEP_CHAIN = 128
 RT_FEAT_MEDIUM_NESTED = 256
@@ -125,6 +126,7 @@ ABI = {
     "rt_pack_tiles_host": (C.c_int, [_DP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _DP]),
     "rt_unpack_tiles_host": (C.c_int, [_DP, C.c_int, C.c_int, C.c_int, C.c_int, _DP]),
     "rt_render_status": (C.c_int, [_VP]),
+    "rt_render_wait_output": (C.c_int, [_VP, _VP]),
     "rt_scene_set_workspace_limit": (C.c_int, [_VP, C.c_size_t]),
     "rt_scene_trim": (C.c_int, [_VP]),
     "rt_scene_workspace_bytes": (C.c_size_t, [_VP]),
@@ -359,6 +361,10 @@ class Scene:
                             stream_ptr=None, flags=0):
         p = rt_render_params(width, height, spp, max_depth, seed, shard[0], shard[1], flags)
         _check(lib().rt_render_tiles_device(self._h, C.byref(cam.c), C.byref(p), d_out_ptr, d_counters_ptr, stream_ptr))
+
+    def wait_output(self, stream_ptr=None):
+        """make `stream` wait for the output of the last render_tiles_device(flags=RT_FLAG_DEFERRED_OUTPUT) (rt_render_wait_output)"""
+        _check(lib().rt_render_wait_output(self._h, stream_ptr))
 
     def last_kernel_ms(self) -> float:
         ms = C.c_float()

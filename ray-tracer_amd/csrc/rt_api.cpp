@@ -25,7 +25,7 @@
 extern "C" int rt_launch_render(const RtLaunch *L, unsigned features, int lens, int count, int ldsnodes, int blocks,
                                 unsigned lds_bytes, void *stream);
 extern "C" int rt_launch_reduce(const double *samples, double *tiles, int n_owned_tiles, int s_count, int first_pass, int last_pass,
-                                int spp, int width, int height, int shard_index, int shard_count, void *stream);
+                                int spp, int width, int height, int shard_index, int shard_count, int narrow_blocks, void *stream);
 extern "C" int rt_kernel_block_size(unsigned features);
 extern "C" int rt_kernel_waves_per_simd(unsigned features);
 extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int ldsnodes, unsigned lds_bytes, int *blocks_per_cu,
@@ -393,6 +393,7 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     rt_scene::RenderSlot &sl = s->slots[slot_index];
     s->last_slot = slot_index;
     sl.events_used = 0;
+    sl.deferred = false;
     s->timed = true;
     if (n_owned == 0) return RT_OK;
     const size_t tile_doubles = (size_t)n_owned * RT_TILE_PIXELS * 3;
@@ -520,13 +521,33 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
         if (rc != 0) return hip_fail((hipError_t)rc, "render_kernel launch");
         HIP_TRY(hipEventRecord(sl.events[(size_t)(2 * pass + 1)], st));
         sl.events_used = 2 * (pass + 1);
+        // RT_FLAG_DEFERRED_OUTPUT: the LAST pass's sums run on the scene's own stream behind the render kernel, so the caller's
+        // stream is free for its next render at once (reduce_kernel is bound by HBM, render_kernel by the VALUs: they overlap);
+        // the output is complete where rt_render_wait_output puts its wait
+        const bool defer = (p->flags & RT_FLAG_DEFERRED_OUTPUT) != 0u && pass == n_pass - 1;
+        hipStream_t rs = st;
+        if (defer) {
+            if (!s->post_stream) HIP_TRY(hipStreamCreateWithFlags(&s->post_stream, hipStreamNonBlocking));
+            HIP_TRY(hipStreamWaitEvent(s->post_stream, sl.events[(size_t)(2 * pass + 1)], 0));
+            rs = s->post_stream;
+        }
+        // deferred: ONE 256-thread group per CU (grid-stride) = one wave per SIMD = the 32 VGPRs that four render waves of 120 leave
+        // free, so the next render_kernel's two workgroups per CU are resident beside it (book-one 1200x800x500: 64.75 ms per step
+        // against 65.85 with the sums on the render stream; two groups per CU, or a reduce_kernel of 36 VGPRs: 65.2)
         rc = rt_launch_reduce(L.samples, (double *)d_tiles_out, n_owned, L.s_count, pass == 0 && !accumulate,
                               pass == n_pass - 1 && finalize, p->spp, p->width,
-                              p->height, p->shard_index, p->shard_count, stream);
+                              p->height, p->shard_index, p->shard_count, defer ? n_cu : 0, (void *)rs);
         if (rc != 0) return hip_fail((hipError_t)rc, "reduce_kernel launch");
+        if (defer) {
+            HIP_TRY(hipEventRecord(sl.done, rs));
+            sl.used = true;
+            sl.deferred = true;
+        }
     }
-    HIP_TRY(hipEventRecord(sl.done, st));
-    sl.used = true;
+    if (!sl.deferred) {
+        HIP_TRY(hipEventRecord(sl.done, st));
+        sl.used = true;
+    }
     rt_launch_config &lc = s->last_launch;
     lc.blocks = last_blocks;
     lc.block_threads = (int)block;
@@ -624,6 +645,16 @@ int rt_render_status(rt_scene *s) {
         if (int e = check_device_status(sl)) rc = e;
     }
     return rc;
+}
+
+int rt_render_wait_output(rt_scene *s, void *stream) {
+    if (!s) return fail(RT_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (!s->timed) return fail(RT_ERR_STATE, "no render has been launched on this scene");
+    HIP_TRY(hipSetDevice(s->device));
+    const rt_scene::RenderSlot &sl = s->slots[s->last_slot];
+    if (sl.used) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, sl.done, 0)); // a no-op when the output was not deferred
+    return RT_OK;
 }
 
 int rt_scene_set_workspace_limit(rt_scene *s, size_t bytes) {

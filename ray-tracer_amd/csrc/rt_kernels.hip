@@ -776,40 +776,47 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
 // One thread per owned pixel; consecutive threads read consecutive 32-byte records.
 __global__ void reduce_kernel(const double *samples, double *tiles, int n_owned_tiles, int s_count, int first_pass,
                               int last_pass, int spp, int width, int height, int tiles_x, int shard_index, int shard_count) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)n_owned_tiles * RT_TILE_PIXELS) return;
-    const size_t k = i / RT_TILE_PIXELS;
-    const int pix = (int)(i % RT_TILE_PIXELS);
-    const int tile = shard_index + (int)k * shard_count;
-    const int x = (tile % tiles_x) * RT_TILE_EDGE + (pix & 7), y = (tile / tiles_x) * RT_TILE_EDGE + (pix >> 3);
-    double *out = tiles + i * 3;
-    if (x >= width || y >= height) {
-        out[0] = out[1] = out[2] = 0.0;
-        return;
+    // grid-stride over the owned pixels: the launch may be the whole image (one thread per pixel) or NARROW (two 256-thread
+    // groups per CU, each thread several pixels) -- the narrow form leaves the CUs to a render_kernel that runs beside it
+    // (RT_FLAG_DEFERRED_OUTPUT) and still reaches the HBM roof (131 k threads x two records in flight)
+    const size_t n_pix = (size_t)n_owned_tiles * RT_TILE_PIXELS, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += stride) {
+        const size_t k = i / RT_TILE_PIXELS;
+        const int pix = (int)(i % RT_TILE_PIXELS);
+        const int tile = shard_index + (int)k * shard_count;
+        const int x = (tile % tiles_x) * RT_TILE_EDGE + (pix & 7), y = (tile / tiles_x) * RT_TILE_EDGE + (pix >> 3);
+        double *out = tiles + i * 3;
+        if (x >= width || y >= height) {
+            out[0] = out[1] = out[2] = 0.0;
+            continue;
+        }
+        double r = 0.0, g = 0.0, b = 0.0;
+        if (!first_pass) {
+            r = out[0];
+            g = out[1];
+            b = out[2];
+        }
+        const double2 *p = reinterpret_cast<const double2 *>(samples + ((size_t)k * (size_t)s_count * RT_TILE_PIXELS + (size_t)pix) * 4);
+        int s = 0;
+        // (one record in flight per thread: the kernel has to fit into the 32 VGPRs per SIMD that four waves of render_kernel leave
+        // free, and 131 k threads x 32 bytes in flight are enough for the HBM roof)
+        for (; s < s_count; ++s) {
+            const double2 a = p[0], c = p[1];
+            r += a.x;
+            g += a.y;
+            b += c.x;
+            p += RT_TILE_PIXELS * 2;
+        }
+        if (last_pass) {
+            const double n = (double)spp;
+            r /= n;
+            g /= n;
+            b /= n;
+        }
+        out[0] = r;
+        out[1] = g;
+        out[2] = b;
     }
-    double r = 0.0, g = 0.0, b = 0.0;
-    if (!first_pass) {
-        r = out[0];
-        g = out[1];
-        b = out[2];
-    }
-    const double2 *p = reinterpret_cast<const double2 *>(samples + ((size_t)k * (size_t)s_count * RT_TILE_PIXELS + (size_t)pix) * 4);
-    for (int s = 0; s < s_count; ++s) {
-        const double2 a = p[0], c = p[1];
-        r += a.x;
-        g += a.y;
-        b += c.x;
-        p += RT_TILE_PIXELS * 2;
-    }
-    if (last_pass) {
-        const double n = (double)spp;
-        r /= n;
-        g /= n;
-        b /= n;
-    }
-    out[0] = r;
-    out[1] = g;
-    out[2] = b;
 }
 
 // gathered shards -> row-major image.  One thread per (pixel, channel).
@@ -964,11 +971,14 @@ extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int 
     return 0;
 }
 
+// narrow_blocks > 0: that many 256-thread groups (grid-stride) instead of one thread per pixel
 extern "C" int rt_launch_reduce(const double *samples, double *tiles, int n_owned_tiles, int s_count, int first_pass, int last_pass,
-                                int spp, int width, int height, int shard_index, int shard_count, void *stream) {
+                                int spp, int width, int height, int shard_index, int shard_count, int narrow_blocks, void *stream) {
     const size_t n = (size_t)n_owned_tiles * RT_TILE_PIXELS;
     const int tiles_x = (width + RT_TILE_EDGE - 1) / RT_TILE_EDGE;
-    hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, samples, tiles,
+    size_t blocks = (n + 255) / 256;
+    if (narrow_blocks > 0 && (size_t)narrow_blocks < blocks) blocks = (size_t)narrow_blocks;
+    hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, samples, tiles,
                        n_owned_tiles, s_count, first_pass, last_pass, spp, width, height, tiles_x, shard_index, shard_count);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

@@ -38,9 +38,11 @@ struct rt_scene {
         void *d_job_counter = nullptr;
         hipEvent_t done = nullptr;
         bool used = false;
+        bool deferred = false; // its last reduce ran on the scene's post stream (RT_FLAG_DEFERRED_OUTPUT)
         std::vector<hipEvent_t> events;
         int events_used = 0;
     };
+    hipStream_t post_stream = nullptr; // deferred reduce_kernel launches
     RenderSlot slots[2];
     int last_slot = 0;
     bool timed = false;
@@ -53,6 +55,8 @@ struct rt_scene {
                 if (*p) (void)hipFree(*p);
                 *p = nullptr;
             }
+            if (post_stream) (void)hipStreamDestroy(post_stream);
+            post_stream = nullptr;
             for (RenderSlot &sl : slots) {
                 if (sl.d_samples) (void)hipFree(sl.d_samples);
                 if (sl.d_job_counter) (void)hipFree(sl.d_job_counter);

@@ -110,6 +110,7 @@ pub const RT_ERR_UNSUPPORTED: c_int = -4;
 pub const RT_ERR_STATE: c_int = -5;
 pub const RT_TILE: c_int = 8;
 pub const RT_FLAG_COUNTERS: c_uint = 1;
+pub const RT_FLAG_DEFERRED_OUTPUT: c_uint = 2;
 
 extern "C" {
     pub fn rt_last_error() -> *const c_char;
@@ -215,6 +216,7 @@ extern "C" {
         image_out: *mut c_double,
     ) -> c_int;
     pub fn rt_render_status(s: *mut rt_scene) -> c_int;
+    pub fn rt_render_wait_output(s: *mut rt_scene, stream: *mut c_void) -> c_int;
     pub fn rt_scene_set_workspace_limit(s: *mut rt_scene, bytes: usize) -> c_int;
     pub fn rt_scene_trim(s: *mut rt_scene) -> c_int;
     pub fn rt_scene_workspace_bytes(s: *const rt_scene) -> usize;

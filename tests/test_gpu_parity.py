@@ -680,6 +680,83 @@ def test_device_renders_in_flight_on_two_streams(rt, scenes, gpu_device):
         assert np.array_equal(im.cpu().numpy().reshape(H, W, 3), ref), (W, H, spp, seed)
 
 
+def test_device_error_word_instead_of_a_hang(rt, scenes, gpu_device, monkeypatch):
+    """A persistent kernel has one failure mode, the hang (round 2, 05:58: the host sized the launch without a region the kernel
+    had grown).  Now (ray-tracer_amd/csrc/rt_lds.h) host and kernel share one layout function, and the kernel
+    checks the bytes it was launched with: a short launch is refused -- RT_ERR_DEVICE, no image, no hang -- and the counting
+    build's watchdog turns a wave that makes no progress into the same error."""
+    sc, cam = scenes.build_product(scenes.cover(1, 1.0), device=gpu_device)
+    ok = sc.render(cam, 64, 64, 4, 50, seed=1)
+    monkeypatch.setenv("RT_TEST_LDS_SHORT", "1")
+    with pytest.raises(rt.RtError) as e:
+        sc.render(cam, 64, 64, 4, 50, seed=1)
+    assert "fewer LDS bytes" in str(e.value)
+    monkeypatch.delenv("RT_TEST_LDS_SHORT")
+    assert np.array_equal(sc.render(cam, 64, 64, 4, 50, seed=1), ok)  # the error word was cleared, the scene still renders
+    # the asynchronous entry: the launch itself succeeds, rt_render_status reports
+    import torch
+    buf = torch.zeros(rt.shard_tile_count(64, 64, 0, 1) * 64 * 3, dtype=torch.float64, device=f"cuda:{gpu_device}")
+    monkeypatch.setenv("RT_TEST_LDS_SHORT", "1")
+    sc.render_tiles_device(cam, 64, 64, 4, 50, 1, (0, 1), buf.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    with pytest.raises(rt.RtError):
+        sc.status()
+    monkeypatch.delenv("RT_TEST_LDS_SHORT")
+    sc.status()
+    # watchdog (counting build): a bound of 3 trips cannot be met by any wave
+    monkeypatch.setenv("RT_TEST_WATCHDOG_TRIPS", "3")
+    with pytest.raises(rt.RtError) as e:
+        sc.render(cam, 64, 64, 4, 50, seed=1, counters=True)
+    assert "no progress" in str(e.value)
+    monkeypatch.delenv("RT_TEST_WATCHDOG_TRIPS")
+    img, cnt = sc.render(cam, 64, 64, 4, 50, seed=1, counters=True)  # the default bound is never reached by a healthy launch
+    assert np.array_equal(img, ok) and cnt["samples"] == 64 * 64 * 4
+
+
+def test_sample_workspace_limit_and_trim(rt, scenes, gpu_device):
+    """the per-sample workspace (32 B per sample of a pass): sized to the render, limited per scene, given back by trim"""
+    sc, cam = scenes.build_product(scenes.book_one(1, 1.5), device=gpu_device)
+    assert sc.workspace_bytes() == 0
+    a = sc.render(cam, 96, 64, 16, 50, seed=2)
+    assert sc.workspace_bytes() == 96 * 64 * 16 * 32 and sc.last_launch_config()["passes"] == 1
+    sc.set_workspace_limit(96 * 64 * 32 * 5)  # five samples per pixel per pass
+    sc.trim()
+    assert sc.workspace_bytes() == 0
+    b = sc.render(cam, 96, 64, 16, 50, seed=2)
+    assert sc.last_launch_config()["passes"] == 4 and sc.workspace_bytes() == 96 * 64 * 5 * 32
+    assert np.array_equal(a, b)
+    sc.set_workspace_limit(0)
+    sc.trim()
+
+
+def test_deferred_output_overlaps_renders_and_changes_nothing(rt, scenes, gpu_device):
+    """RT_FLAG_DEFERRED_OUTPUT: render_kernel on the caller's stream, the sums of its sample records behind it on the scene's own
+    stream (so that the next render starts at once); rt_render_wait_output makes a stream wait for them.  Three renders in flight
+    back to back -- different seeds, alternating workspace slots and output buffers -- give the images of plain rt_render."""
+    import torch
+    W, H, spp, depth = 160, 96, 24, 50
+    sc, cam = scenes.build_product(scenes.book_one(1, W / H), device=gpu_device)
+    want = [sc.render(cam, W, H, spp, depth, seed=s) for s in (1, 2, 3)]
+    dev = torch.device("cuda", gpu_device)
+    n_tiles = rt.shard_tile_count(W, H, 0, 1)
+    bufs = [torch.zeros(n_tiles * 64 * 3, dtype=torch.float64, device=dev) for _ in range(3)]
+    imgs = [torch.zeros(H * W * 3, dtype=torch.float64, device=dev) for _ in range(3)]
+    rs, post = torch.cuda.current_stream(), torch.cuda.Stream(device=dev)
+    for i, seed in enumerate((1, 2, 3)):
+        sc.render_tiles_device(cam, W, H, spp, depth, seed, (0, 1), bufs[i].data_ptr(), None, rs.cuda_stream, flags=rt.RT_FLAG_DEFERRED_OUTPUT)
+        sc.wait_output(post.cuda_stream)
+        rt.unpack_tiles_device(bufs[i].data_ptr(), n_tiles, 1, W, H, imgs[i].data_ptr(), post.cuda_stream)
+    torch.cuda.synchronize()
+    sc.status()
+    for i in range(3):
+        assert np.array_equal(imgs[i].cpu().numpy().reshape(H, W, 3), want[i]), i
+    # without the flag rt_render_wait_output is a harmless no-op
+    sc.render_tiles_device(cam, W, H, spp, depth, 1, (0, 1), bufs[0].data_ptr(), None, rs.cuda_stream)
+    sc.wait_output(rs.cuda_stream)
+    rt.unpack_tiles_device(bufs[0].data_ptr(), n_tiles, 1, W, H, imgs[0].data_ptr(), rs.cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(imgs[0].cpu().numpy().reshape(H, W, 3), want[0])
+
+
 def test_bench_two_ranks_rehearsal(gpu_device):
     """bench.py's N > 1 path end to end on this one-GPU box: two processes (torch.distributed.run, gloo, both on cuda:0) render
     their tile shards with the HIP kernel, gather, un-permute; rank 0 reports each rank's step anatomy and checks the
