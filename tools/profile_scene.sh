@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box: rocprofv3 kernel-trace stats + separate PMC passes (never --pmc together with trace
 # domains; the program directly after `--`) of bench.py for one scene.
-# Usage: tools/profile_r02.sh <tag> <scene> <W> <H> <spp>     -> gpurun_out/prof_<tag>/summary/
+# Usage: tools/profile_scene.sh <tag> <scene> <W> <H> <spp>     -> gpurun_out/prof_<tag>/summary/
 set -u
 TAG=$1; SCENE=$2; W=$3; H=$4; SPP=$5
 R=${GRAFT_REPO_ROOT:-$(pwd)}

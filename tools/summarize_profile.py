@@ -208,8 +208,16 @@ def main():
         total_issue = sum(issue.values())
         frac = total_issue / (N_SIMD * elapsed_cycles)
         lane = res.get("valu_lane_utilisation")
+        n_other, rest = counts["other"], total_issue - issue["other"]
+        busy = mean("SQ_ACTIVE_INST_VALU")
         res["valu_issue_roofline"] = {
             "bound": "valu_issue",
+            # no hardware counter classifies moves / selects / compares / lane operations: the envelope prices the unclassified
+            # instructions at the cheapest (2) and the dearest (4 cycles) of them instead of the static-mix average
+            "frac_envelope_other_at_2_and_4_cycles": [(rest + 2.0 * n_other) / (N_SIMD * elapsed_cycles), (rest + 4.0 * n_other) / (N_SIMD * elapsed_cycles)],
+            "f64_math_frac": (issue["f64"] + issue["trans_f64"]) / (N_SIMD * elapsed_cycles),
+            # quad-cycles with a VALU instruction in flight x 4 over the SIMD-cycles of the launch: the hardware's own measure
+            "valu_busy_frac_pmc": (busy * 4.0 / (N_SIMD * elapsed_cycles)) if busy else None,
             "wave_instructions_per_launch": counts, "issue_cycles_per_instruction": {k: prices[k] for k in counts},
             "prices_source": prices["source"],
             "issue_cycles_per_launch": issue, "issue_cycles_total": total_issue,
