@@ -434,6 +434,15 @@ def test_random_scenes_match_oracle(rt, scenes, oracle, gpu_device, seed):
     _close(img, ref, max_bad=4)
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_random_scenes_with_deep_chains_and_nested_media_match_oracle(rt, scenes, oracle, gpu_device, seed):
+    from test_random_scenes import random_scene_r3
+    d = random_scene_r3(scenes, seed)
+    sc, cam = scenes.build_product(d, device=gpu_device)
+    img = sc.render(cam, 64, 48, 6, 40, seed=seed + 100)
+    _close(img, oracle.build_oracle(d, bvh_seed=seed).render(64, 48, 6, 40, seed=seed + 100, iterative=True, nthreads=8), max_bad=4)
+
+
 def test_config5_shape_3840x2160_sharded_multipass(rt, scenes, oracle, gpu_device, monkeypatch):
     """configs[4] shape: 3840x2160 tile-sharded 8 ways (the shards rendered one after another on this one
     GPU), sample workspace capped so that every shard needs several passes; 6 of the 2000 spp."""
@@ -832,7 +841,12 @@ def test_bench_line_contract(gpu_device):
         assert rf["reason"]  # profile of another build / workload: said so, no number
     else:
         assert 0.3 < rf["frac"] <= 1.0 and 0.1 < rf["useful_frac"] <= rf["frac"]
-        assert rf["source"].startswith("profiles/r02_book_one/summary.json")
+        assert rf["source"].startswith("profiles/r03_book_one/summary.json")
         assert 15.36e9 <= rf["traffic"] < 1.5 * 15.36e9  # one 32-byte record per sample, written once
+        lo, hi = rf["frac_envelope_other_at_2_and_4_cycles"]  # the unclassified instructions at their cheapest / dearest price
+        assert lo < rf["frac"] < hi <= 1.0
+        assert 0.1 < rf["f64_math_frac"] < rf["frac"]          # the reference's own binary64 arithmetic alone
+        assert rf["frac"] < rf["valu_busy_frac_pmc"] <= 1.0     # the hardware's VALU-busy share bounds the instruction model
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "Msamples/s" and cb["cores"] >= 1 and 0 < cb["value"] < d["value"] / 10
+    assert cb["cpu_model"] and cb["configs0_full"]["value"] > 0 and "configs[0]" in cb["configs0_full"]["workload"]

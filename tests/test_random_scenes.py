@@ -114,3 +114,68 @@ def test_random_scene_bit_exact(scenes, oracle, lane_emul, seed):
     assert np.array_equal(img, ref, equal_nan=True)
     assert cnt["segments"] == ocnt["segments"]
     assert high <= 24
+
+
+def random_scene_r3(scenes, seed):
+    """random_scene plus what round 3 lifted: primitives and media behind 5-9 transform levels (RT_FEAT_DEEP_CHAIN) and media
+    inside the boundary of media, two or three levels, directly or through a node (RT_FEAT_MEDIUM_NESTED)"""
+    d = random_scene(scenes, seed)
+    rng = np.random.default_rng(seed + 77777)
+    axes = [(1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)]
+
+    def step():
+        t = scenes.mat4_translation(rng.uniform(-0.3, 0.3, 3))
+        c = rng.integers(0, 3)
+        if c == 0:
+            return t
+        m = scenes.mat4_multiplied(t, scenes.mat4_rotation(float(rng.uniform(-1, 1)), axes[rng.integers(3)]))
+        if c == 2:
+            s = [0.0] * 16
+            s[0], s[5], s[10], s[15] = float(rng.uniform(0.7, 1.4)), float(rng.uniform(0.7, 1.4)), float(rng.uniform(0.7, 1.4)), 1.0
+            m = scenes.mat4_multiplied(m, s)
+        return m
+
+    def behind(geo, levels):
+        for _ in range(levels):
+            geo = d.geom("transformed", geo, step())
+        return geo
+
+    def place():
+        return scenes.mat4_translation(rng.uniform(-5, 5, 3) + np.array([0, 0, 11.0]))
+
+    solid = [i for i, t in enumerate(d.textures) if t[0] == "solid"]
+    for _ in range(int(rng.integers(1, 4))):  # deep chains
+        g = rng.integers(0, 3)
+        geo = d.geom("sphere", float(rng.uniform(0.4, 1.2))) if g == 0 else (
+            d.geom("rectangle", float(rng.uniform(1, 3)), float(rng.uniform(1, 3))) if g == 1 else
+            d.geom("cube", float(rng.uniform(0.6, 1.6)), float(rng.uniform(0.6, 1.6)), float(rng.uniform(0.6, 1.6))))
+        kinds = ("lambertian", "metal", "dielectric")
+        k = kinds[rng.integers(3)]
+        mat = d.mat("dielectric", 1.5) if k == "dielectric" else (d.mat("metal", int(solid[0]), 0.2) if k == "metal" else d.mat("lambertian", int(solid[1])))
+        d.sprite(behind(geo, int(rng.integers(4, 9))), mat, place())
+    if rng.random() < 0.8:  # nested media
+        inner = d.geom("medium", d.geom("sphere", float(rng.uniform(0.6, 1.2))) if rng.random() < 0.6 else
+                       d.geom("cube", float(rng.uniform(0.8, 1.6)), float(rng.uniform(0.8, 1.6)), float(rng.uniform(0.8, 1.6))), float(rng.uniform(0.5, 3.0)))
+        c = rng.integers(0, 3)
+        if c == 0:
+            boundary = inner
+        elif c == 1:
+            boundary = d.geom("medium", behind(inner, int(rng.integers(0, 3))), float(rng.uniform(0.5, 2.0)))  # three levels in all
+        else:
+            boundary = d.geom("bvh", [d.sprite(inner, None, step()), d.sprite(d.geom("sphere", float(rng.uniform(0.4, 0.9))), None, step())])
+        geo = d.geom("medium", boundary, float(rng.uniform(0.3, 1.5)))
+        if rng.random() < 0.5:
+            geo = behind(geo, int(rng.integers(1, 6)))
+        d.sprite(geo, d.mat("isotropic", int(solid[rng.integers(len(solid))])), place())
+    return d
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_scene_with_deep_chains_and_nested_media_bit_exact(scenes, oracle, lane_emul, rt, seed):
+    d = random_scene_r3(scenes, seed)
+    sc, cam = scenes.build_product(d, device=-1)
+    assert sc.info()["feature_mask"] & (rt.RT_FEAT_DEEP_CHAIN | rt.RT_FEAT_MEDIUM_NESTED)
+    img, cnt, high = lane_emul.render(sc, cam, 32, 24, 3, 40, seed=seed + 100)
+    ref, ocnt = oracle.build_oracle(d, bvh_seed=seed).render(32, 24, 3, 40, seed=seed + 100, iterative=True, nthreads=4, counters=True)
+    assert np.array_equal(img, ref, equal_nan=True)
+    assert cnt["segments"] == ocnt["segments"]

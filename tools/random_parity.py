@@ -18,7 +18,7 @@ from __graft_entry__ import load_package  # noqa: E402
 rt = load_package()
 scenes = importlib.import_module("ray_tracer_amd.scenes")
 import oracle_binding as oracle  # noqa: E402
-from test_random_scenes import random_scene  # noqa: E402
+from test_random_scenes import random_scene, random_scene_r3  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 threads = min(256, os.cpu_count() or 8)
@@ -26,7 +26,8 @@ t0 = time.time()
 worst_mae, worst_max, exact, bad_pixels, pixels = 0.0, 0.0, 0, 0, 0
 hist = {}
 for seed in range(100, 100 + N):
-    d = random_scene(scenes, seed)
+    # every second scene also carries deep transform chains and media inside the boundary of media (round 3)
+    d = random_scene_r3(scenes, seed) if seed % 2 else random_scene(scenes, seed)
     rng = np.random.default_rng(seed)
     W, H, spp = int(rng.integers(24, 96)), int(rng.integers(16, 72)), int(rng.integers(2, 12))
     sc, cam = scenes.build_product(d, device=0)
@@ -45,7 +46,7 @@ for seed in range(100, 100 + N):
     if not finite or mae > 1e-4:
         print("FAIL seed", seed, W, H, spp, mae, nbad, flush=True)
         sys.exit(1)
-res = {"scenes": N, "bit_identical_scenes": exact, "pixels": pixels, "pixels_differing_by_more_than_1e-12": bad_pixels,
+res = {"scenes": N, "of_them_with_deep_chains_and_nested_media": N // 2, "bit_identical_scenes": exact, "pixels": pixels, "pixels_differing_by_more_than_1e-12": bad_pixels,
        "worst_mean_abs_error": worst_mae, "worst_abs_diff": worst_max, "differing_pixels_per_scene_histogram": {str(k): v for k, v in sorted(hist.items())},
        "seconds": time.time() - t0, "bar": "mean abs error <= 1e-4 per scene"}
 print(res)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense a tools/profile_r02.sh (or tools/profile.sh) output directory into profiles-ready files:
+"""Condense a tools/profile_scene.sh output directory into profiles-ready files:
 summary/summary.json + summary/kernel_stats.csv.
 
 summary.json holds, for the timed render_kernel (COUNT = false instantiation):
