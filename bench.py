@@ -7,9 +7,13 @@ tile_id % N == rank into a packed device buffer (hand-written HIP kernel through
 the C ABI), one RCCL gather brings the shards to rank 0, one small kernel
 un-permutes them and rank 0 copies the framebuffer to the host.  Total work is
 fixed as N grows (strong scaling).  Inputs (the committed scene) are resident in
-HBM before the timed region.
+HBM before the timed region.  Consecutive steps are pipelined: a step's render kernel runs
+on the render stream, everything behind it (the sums of its sample records, gather, unpack,
+copy) on a second stream, beside the next step's render kernel (--no-defer switches that off);
+every step's image is complete on the host inside the timed region.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          (starts its own N ranks: a child torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -17,11 +21,14 @@ The JSON line carries
   roofline      what bounds render_kernel: VALU issue.  The scene (< 1 MB) lives in LDS / L1 / L2, so HBM is not the
                 roof (0.27 TB/s of real traffic = 3 % of peak; the algorithmic bytes of SURVEY.md 8(d) are kept as the
                 secondary "hbm_equivalent" object).  achieved = sum over instruction classes of (wave instructions per
-                launch, rocprofv3 SQ_INSTS_VALU_* of profiles/r02_<scene>/summary.json) x (issue cycles per instruction
+                launch, rocprofv3 SQ_INSTS_VALU_* of profiles/r03_<scene>/summary.json) x (issue cycles per instruction
                 per SIMD measured on the MI355X, profiles/r02_valu_issue.json) / (kernel duration measured live here
-                with HIP events); peak = 1024 SIMDs x 2.4 GHz.  The counts are only used when the profile was taken
-                with THIS build of the library (rt_version source hash) on this workload; otherwise frac is null.
-  cpu_baseline  the oracle in reference form on the host cores, on a bounded sample of the same workload.
+                with HIP events); peak = 1024 SIMDs x 2.4 GHz.  Beside frac: its envelope with the unclassified half of the
+                instructions at 2 and at 4 cycles, f64_math_frac (binary64 arithmetic alone) and valu_busy_frac_pmc (the
+                hardware's own VALU-busy share of the profiled launch: the figure that bounds).  The counts are only used
+                when the profile was taken with the loaded KERNELS (rt_version kernel hash) on this workload; otherwise null.
+  cpu_baseline  the oracle in reference form on the host cores (count and CPU model stated), on a bounded sample of the same
+                workload, plus BASELINE configs[0] (400x225x50, depth 50) in full.
 With N > 1 every rank also reports render / gather / unpack / copy times of one extra, untimed step, and rank 0 checks the
 gathered image against a single-GPU render of the whole image.
 """
