@@ -52,6 +52,36 @@
 #define RT_HD static inline
 #endif
 
+/* RT_DEVICE_MATH selects the bit-level forms the kernels compute with (funnel-shift rotations, numbers assembled from their
+ * bits; rt_lane.h adds the shared-reciprocal divisions).  It is on for device code.  A HOST build may define
+ * RT_EMULATE_DEVICE_MATH to compile the very same forms with portable stand-ins for the intrinsics, so that the CPU suite
+ * executes them too (tests/lane_emul.cpp is built both ways; tests/test_lane_parity_cpu.py compares both with the oracle). */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_DEVICE_MATH 1
+#define RT_ALIGNBIT(a, b, s) __builtin_amdgcn_alignbit((a), (b), (s))
+#define RT_HILO_TO_DOUBLE(hi, lo) __hiloint2double((int)(hi), (int)(lo))
+#define RT_DOUBLE_HI(x) ((uint32_t)__double2hiint(x))
+#elif defined(RT_EMULATE_DEVICE_MATH)
+#define RT_DEVICE_MATH 1
+static inline uint32_t rt_emul_alignbit(uint32_t a, uint32_t b, uint32_t s) { /* v_alignbit_b32: low word of {a, b} >> s[4:0] */
+    return (uint32_t)(((((uint64_t)a) << 32) | (uint64_t)b) >> (s & 31u));
+}
+static inline double rt_emul_hilo_to_double(uint32_t hi, uint32_t lo) {
+    const uint64_t b = ((uint64_t)hi << 32) | (uint64_t)lo;
+    double d;
+    memcpy(&d, &b, sizeof d);
+    return d;
+}
+static inline uint32_t rt_emul_double_hi(double x) {
+    uint64_t b;
+    memcpy(&b, &x, sizeof b);
+    return (uint32_t)(b >> 32);
+}
+#define RT_ALIGNBIT(a, b, s) rt_emul_alignbit((a), (b), (s))
+#define RT_HILO_TO_DOUBLE(hi, lo) rt_emul_hilo_to_double((uint32_t)(hi), (uint32_t)(lo))
+#define RT_DOUBLE_HI(x) rt_emul_double_hi(x)
+#endif
+
 #define RT_RNG_GAMMA 0x9E3779B97F4A7C15ull
 #define RT_RNG_STREAM_SHIFT 24
 #define RT_RNG_KEYED_BASE (1ull << 23)
@@ -73,7 +103,7 @@ RT_HD uint64_t rt_rng_base(uint64_t seed, uint64_t stream) {
     return rt_mix64(seed) + (stream << RT_RNG_STREAM_SHIFT) * RT_RNG_GAMMA;
 }
 
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(RT_DEVICE_MATH)
 /* two funnel shifts (v_alignbit_b32: the low word of {a, b} >> s) instead of 64-bit shifts and an or */
 RT_HD uint64_t rt_rotl64(uint64_t x, int k) {
     uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
@@ -84,7 +114,7 @@ RT_HD uint64_t rt_rotl64(uint64_t x, int k) {
         k -= 32;
     }
     if (k == 0) return ((uint64_t)hi << 32) | lo;
-    const uint32_t nh = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(32 - k)), nl = __builtin_amdgcn_alignbit(lo, hi, (uint32_t)(32 - k));
+    const uint32_t nh = RT_ALIGNBIT(hi, lo, (uint32_t)(32 - k)), nl = RT_ALIGNBIT(lo, hi, (uint32_t)(32 - k));
     return ((uint64_t)nh << 32) | nl;
 }
 #else
@@ -172,10 +202,10 @@ RT_HD double rt_u64_to_unit53(uint64_t x) {
  * builds the same number from bits: 1.m = 1 + (k mod 2^52) * 2^-52, minus 1 when bit 52 of k is set, minus 2 when it is not --
  * both differences are exact (Sterbenz) -- instead of a 64-bit integer conversion, two multiplications and a subtraction. */
 RT_HD double rt_u64_to_pm1(uint64_t x) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(RT_DEVICE_MATH)
     const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
     const uint32_t mhi = 0x3FF00000u | ((hi >> 11) & 0xFFFFFu), mlo = (hi << 21) | (lo >> 11);
-    const double one_m = __hiloint2double((int)mhi, (int)mlo);
+    const double one_m = RT_HILO_TO_DOUBLE(mhi, mlo);
     return one_m - (((int32_t)hi < 0) ? 1.0 : 2.0);
 #else
     return rt_u64_to_unit53(x) * 2.0 - 1.0;

@@ -19,11 +19,43 @@
 
 namespace rtl {
 
+#define RTL_INF (__builtin_huge_val())
+// The seed of the shared-reciprocal divisions below.  Device: v_rcp_f64 (relative error <= 2^-23 by the ISA manual's bound).
+// Host emulation (RT_EMULATE_DEVICE_MATH, include/rt_rng.h): the exact reciprocal spoilt to that bound in a chosen direction
+// -- low 29 mantissa bits cleared, set, or either by a hash of the operand (rtl_emul_rcp_mode 0 / 1 / 2) -- so that the CPU suite
+// shows the refinement reaching the correctly rounded quotient from ANY seed of the documented accuracy, not from one
+// implementation's.
 #if defined(__HIP_DEVICE_COMPILE__)
-#define RTL_INF (__builtin_huge_val())
-#else
-#define RTL_INF (__builtin_huge_val())
+#define RTL_RCP64(x) __builtin_amdgcn_rcp(x)
+#define RTL_OUT_OF_LINE static __device__ __attribute__((noinline))
+#elif defined(RT_EMULATE_DEVICE_MATH)
+extern int rtl_emul_rcp_mode;
+extern unsigned long long rtl_emul_rcp_calls;
+static inline double rtl_emul_rcp64(double x) {
+    double r = 1.0 / x;
+    uint64_t b;
+    memcpy(&b, &r, sizeof b);
+    const bool up = rtl_emul_rcp_mode == 1 || (rtl_emul_rcp_mode == 2 && ((b * 0x9E3779B97F4A7C15ull) >> 63));
+    b = up ? (b | 0x1FFFFFFFull) : (b & ~0x1FFFFFFFull);
+    memcpy(&r, &b, sizeof b);
+    ++rtl_emul_rcp_calls;
+    return r;
+}
+static inline float rtl_emul_rcp32(float x) { // v_rcp_f32's 1 ulp: the correctly rounded reciprocal moved one float down or up
+    float r = 1.0f / x;
+    if (!(r == r) || r == 0.0f || r - r != 0.0f) return r; // NaN, zero, infinity as they are
+    uint32_t b;
+    memcpy(&b, &r, sizeof b);
+    const bool up = rtl_emul_rcp_mode == 1 || (rtl_emul_rcp_mode == 2 && ((b * 0x9E3779B9u) >> 31));
+    b = up ? b + 1u : b - 1u; // in magnitude
+    memcpy(&r, &b, sizeof b);
+    return r;
+}
+#define RTL_RCP64(x) rtl::rtl_emul_rcp64(x)
+#define RTL_OUT_OF_LINE static inline
 #endif
+RT_HD uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+RT_HD uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 #define RTL_PI 3.14159265358979323846264338327950288
 #define RTL_EPS 1e-6 /* src/geometry.rs:57,62,159 */
 
@@ -49,17 +81,17 @@ RT_HD V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
 // mul + fma + fma with exactly the instructions and operands the full expansion would use (same bits by construction; the
 // quotients stay correctly rounded, tests/test_gpu_parity.py::test_device_sqrt_div_correctly_rounded and every bit-exact
 // image test).  Operands outside [2^-500, 2^256] in magnitude (zero, denormal, huge) take the ordinary division.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_PLAIN_DIV3)
+#if defined(RT_DEVICE_MATH) && !defined(RT_PLAIN_DIV3)
 // (out of line: inlined at every division site, the ordinary divisions cost registers the hot path needs)
-static __device__ __attribute__((noinline)) V3 div3_ordinary(V3 a, double s) { return mk(a.x / s, a.y / s, a.z / s); }
+RTL_OUT_OF_LINE V3 div3_ordinary(V3 a, double s) { return mk(a.x / s, a.y / s, a.z / s); }
 RT_HD V3 operator/(V3 a, double s) {
     // every operand's biased exponent in [523, 1279]: the three numerators through their min / max
-    const uint32_t ex = (uint32_t)__double2hiint(a.x) & 0x7FF00000u, ey = (uint32_t)__double2hiint(a.y) & 0x7FF00000u,
-                   ez = (uint32_t)__double2hiint(a.z) & 0x7FF00000u, es = (uint32_t)__double2hiint(s) & 0x7FF00000u;
-    const uint32_t lo = min(min(ex, ey), min(ez, es)), hi = max(max(ex, ey), max(ez, es));
+    const uint32_t ex = RT_DOUBLE_HI(a.x) & 0x7FF00000u, ey = RT_DOUBLE_HI(a.y) & 0x7FF00000u,
+                   ez = RT_DOUBLE_HI(a.z) & 0x7FF00000u, es = RT_DOUBLE_HI(s) & 0x7FF00000u;
+    const uint32_t lo = umin(umin(ex, ey), umin(ez, es)), hi = umax(umax(ex, ey), umax(ez, es));
     if (lo >= 0x20B00000u && hi <= 0x4FF00000u) {
         const double ns = -s;
-        const double r0 = __builtin_amdgcn_rcp(s);
+        const double r0 = RTL_RCP64(s);
         const double f0 = fma(ns, r0, 1.0);
         const double r1 = fma(r0, f0, r0);
         const double f1 = fma(ns, r1, 1.0);
@@ -198,19 +230,19 @@ RT_HD void camera_ray(const RtCameraD &c, double u, double v, Rng &g, V3 *o, V3 
 struct Roots {
     double t1, t2;
 };
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_PLAIN_DIV3)
-static __device__ __attribute__((noinline)) Roots roots_ordinary(double n1, double n2, double den) {
+#if defined(RT_DEVICE_MATH) && !defined(RT_PLAIN_DIV3)
+RTL_OUT_OF_LINE Roots roots_ordinary(double n1, double n2, double den) {
     Roots r;
     r.t1 = n1 / den;
     r.t2 = n2 / den;
     return r;
 }
 RT_HD Roots sphere_roots(double n1, double n2, double den) {
-    const uint32_t e1 = (uint32_t)__double2hiint(n1) & 0x7FF00000u, e2 = (uint32_t)__double2hiint(n2) & 0x7FF00000u,
-                   ed = (uint32_t)__double2hiint(den) & 0x7FF00000u;
-    if (ed - 0x39B00000u <= 0x0C800000u && max(e1, e2) <= 0x4FF00000u) { // biased exponent of den in [923, 1123], of n1, n2 <= 1279
+    const uint32_t e1 = RT_DOUBLE_HI(n1) & 0x7FF00000u, e2 = RT_DOUBLE_HI(n2) & 0x7FF00000u,
+                   ed = RT_DOUBLE_HI(den) & 0x7FF00000u;
+    if (ed - 0x39B00000u <= 0x0C800000u && umax(e1, e2) <= 0x4FF00000u) { // biased exponent of den in [923, 1123], of n1, n2 <= 1279
         const double nd = -den;
-        const double r0 = __builtin_amdgcn_rcp(den);
+        const double r0 = RTL_RCP64(den);
         const double f0 = fma(nd, r0, 1.0);
         const double r1 = fma(r0, f0, r0);
         const double f1 = fma(nd, r1, 1.0);
@@ -239,14 +271,14 @@ RT_HD Roots sphere_roots(double n1, double n2, double den) {
 // sphere's centre and radius <= 2^100: then |b| <= 2^155, disc <= 2^311, both numerators <= 2^157 < 2^256.
 #define RTL_NAN (__builtin_nan(""))
 RT_HD double world_roots_rcp(const RtLaunch &L, V3 o, double a) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_PLAIN_DIV3)
+#if defined(RT_DEVICE_MATH) && !defined(RT_PLAIN_DIV3)
     const double den = 2.0 * a;
-    const uint32_t ed = (uint32_t)__double2hiint(den) & 0x7FF00000u;
-    const uint32_t eo = max(max((uint32_t)__double2hiint(o.x) & 0x7FF00000u, (uint32_t)__double2hiint(o.y) & 0x7FF00000u),
-                            (uint32_t)__double2hiint(o.z) & 0x7FF00000u);
+    const uint32_t ed = RT_DOUBLE_HI(den) & 0x7FF00000u;
+    const uint32_t eo = umax(umax(RT_DOUBLE_HI(o.x) & 0x7FF00000u, RT_DOUBLE_HI(o.y) & 0x7FF00000u),
+                            RT_DOUBLE_HI(o.z) & 0x7FF00000u);
     if (L.world_mid && ed - 0x39B00000u <= 0x0C800000u && eo <= 0x46300000u) { // den: biased exponent in [923, 1123]; o: <= 1123
         const double nd = -den;
-        const double r0 = __builtin_amdgcn_rcp(den);
+        const double r0 = RTL_RCP64(den);
         const double f0 = fma(nd, r0, 1.0);
         const double r1 = fma(r0, f0, r0);
         const double f1 = fma(nd, r1, 1.0);
@@ -266,7 +298,7 @@ RT_HD bool sphere_t(V3 oc, V3 d, double a, double radius, double *t_out, double 
     if (disc < 0.0) return false;
     double sq = sqrt(disc);
     Roots rt;
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_PLAIN_DIV3)
+#if defined(RT_DEVICE_MATH) && !defined(RT_PLAIN_DIV3)
     if (r2a == r2a) {
         const double n1 = -b - sq, n2 = -b + sq, nd = -(2.0 * a);
         const double q1 = n1 * r2a, q2 = n2 * r2a;
@@ -709,6 +741,8 @@ RT_HD float up32(double t) { // >= t in binary32, with room for the ~3e-7 relati
 RT_HD float rcp32(float x) { // 1/x to 1 ulp: v_rcp_f32 on the device (culling only; covered by the slack below)
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_rcpf(x);
+#elif defined(RT_EMULATE_DEVICE_MATH)
+    return rtl_emul_rcp32(x);
 #else
     return 1.0f / x;
 #endif

@@ -69,6 +69,14 @@ def lane_emul(rt):
 
 
 @pytest.fixture(scope="session")
+def lane_devmath(lane_emul):
+    """the same harness compiled with the DEVICE's arithmetic forms (tests/Makefile, -DRT_EMULATE_DEVICE_MATH)"""
+    ns = lane_emul.load("liblane_emul_devmath.so")
+    assert ns.device_math and not lane_emul.device_math
+    return ns
+
+
+@pytest.fixture(scope="session")
 def gpu_device(rt):
     n = rt.device_count()
     if n < 1:

@@ -4,12 +4,24 @@
 // the BVH and the lane arithmetic can be diffed against the oracle on a machine
 // without a GPU.  It is not part of librt_mi355x.so and nothing in the product
 // calls it; GPU parity is established separately by the `-m gpu` tests.
+//
+// Built twice (tests/Makefile): liblane_emul.so takes rt_lane.h's host forms (plain divisions, 64-bit shifts); with
+// -DRT_EMULATE_DEVICE_MATH liblane_emul_devmath.so takes the DEVICE forms -- the shared-reciprocal divisions, the funnel-shift
+// rotations, the numbers assembled from bits -- with portable stand-ins for the three intrinsics (include/rt_rng.h, rt_lane.h:
+// RTL_RCP64 is a reciprocal deliberately spoilt to v_rcp_f64's documented error bound).  Both have to match the oracle bit for bit.
 #include "../ray-tracer_amd/csrc/rt_lane.h"
 #include "../ray-tracer_amd/csrc/rt_lds.h"
 #include "../ray-tracer_amd/csrc/rt_scene_priv.h"
 #include "../include/rt_mi355x.h"
 
 #include <cstring>
+
+#if defined(RT_EMULATE_DEVICE_MATH)
+namespace rtl {
+int rtl_emul_rcp_mode = 0;
+unsigned long long rtl_emul_rcp_calls = 0;
+} // namespace rtl
+#endif
 
 namespace {
 // the LDS stacks of rt_kernels.hip in host memory: the 16-bit form truncates tnear exactly as the device does
@@ -205,4 +217,60 @@ extern "C" void lane_emul_lds_layout(unsigned stack_entries, unsigned block, uns
     out[6] = rt_lds_layout_aligned(l) ? 1u : 0u;
     out[7] = cap;
     out[8] = eff;
+}
+
+// ---- which arithmetic this build carries, and its pieces one at a time ----
+extern "C" int lane_emul_device_math(void) {
+#if defined(RT_EMULATE_DEVICE_MATH)
+    return 1;
+#else
+    return 0;
+#endif
+}
+// direction in which the emulated v_rcp_f64 errs: 0 down, 1 up, 2 either (by a hash of the value); no effect on the host-form build
+extern "C" void lane_emul_set_rcp_mode(int mode) {
+#if defined(RT_EMULATE_DEVICE_MATH)
+    rtl::rtl_emul_rcp_mode = mode;
+#else
+    (void)mode;
+#endif
+}
+extern "C" unsigned long long lane_emul_rcp_calls(void) { // shared-reciprocal divisions taken so far (0 for the host-form build)
+#if defined(RT_EMULATE_DEVICE_MATH)
+    return rtl::rtl_emul_rcp_calls;
+#else
+    return 0ull;
+#endif
+}
+// n triples a / s through rtl::operator/ (Vec3 / f64)
+extern "C" void lane_emul_div3(long n, const double *a, const double *s, double *out) {
+    for (long i = 0; i < n; ++i) {
+        const rtl::V3 q = rtl::mk(a[3 * i], a[3 * i + 1], a[3 * i + 2]) / s[i];
+        out[3 * i] = q.x, out[3 * i + 1] = q.y, out[3 * i + 2] = q.z;
+    }
+}
+// n root pairs (n1 / den, n2 / den) through rtl::sphere_roots
+extern "C" void lane_emul_sphere_roots(long n, const double *n1, const double *n2, const double *den, double *out) {
+    for (long i = 0; i < n; ++i) {
+        const rtl::Roots r = rtl::sphere_roots(n1[i], n2[i], den[i]);
+        out[2 * i] = r.t1, out[2 * i + 1] = r.t2;
+    }
+}
+// Sphere::hit's parametric result with the segment's shared reciprocal (world_roots_rcp), as a world-space sphere is tested
+// during traversal: out = t, or NaN for a miss
+extern "C" void lane_emul_sphere_t_world(long n, const double *oc, const double *d, const double *radius, double *out) {
+    RtLaunch L{};
+    L.world_mid = 1;
+    for (long i = 0; i < n; ++i) {
+        const rtl::V3 o = rtl::mk(oc[3 * i], oc[3 * i + 1], oc[3 * i + 2]), dir = rtl::mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        const double a = rtl::dot(dir, dir);
+        double t = 0.0;
+        out[i] = rtl::sphere_t(o, dir, a, radius[i], &t, rtl::world_roots_rcp(L, o, a)) ? t : __builtin_nan("");
+    }
+}
+extern "C" void lane_emul_rng_forms(long n, const uint64_t *x, uint64_t *rot24, uint64_t *rot37, uint64_t *rot16, double *pm1) {
+    for (long i = 0; i < n; ++i) {
+        rot24[i] = rt_rotl64(x[i], 24), rot37[i] = rt_rotl64(x[i], 37), rot16[i] = rt_rotl64(x[i], 16);
+        pm1[i] = rt_u64_to_pm1(x[i]);
+    }
 }
