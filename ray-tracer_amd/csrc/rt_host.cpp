@@ -995,114 +995,6 @@ struct Builder {
     }
 };
 
-// ---- reinsertion: the top-down tree's inner-node area brought down by moving subtrees ----
-// Every leaf is one prim, so a segment's expected work is (sum of the INNER nodes' areas) / area(root) node steps plus a part
-// the topology cannot change (a leaf is reached when its own box is hit).  The sweep build decides each split with the
-// linear-cost estimate n * area; afterwards subtrees are taken out and put back where they enlarge their new ancestors
-// least (Bittner, Hapala, Havran 2013 -- restated; exhaustive search with a bound, the trees here have a few thousand nodes).
-// The flat prim set, the leaf boxes and hence every result are untouched; only the number of node steps moves.
-struct Reinserter {
-    struct N {
-        Aabb box;
-        int parent = -1, child[2] = {-1, -1};
-        int prim = -1; // >= 0: leaf
-        int height = 0, depth = 0;
-    };
-    std::vector<N> t;
-    int root = -1, depth_limit = 0;
-
-    static double area(const Aabb &b) { return Builder::area(b); }
-
-    int import(const std::vector<HostNode> &hn, const std::vector<Aabb> &bounds, int32_t ref, int parent) {
-        const int me = (int)t.size();
-        t.emplace_back();
-        t[(size_t)me].parent = parent;
-        if (ref < 0) {
-            t[(size_t)me].prim = ~ref;
-            t[(size_t)me].box = bounds[(size_t)~ref];
-            return me;
-        }
-        const int a = import(hn, bounds, hn[(size_t)ref].child[0], me), b = import(hn, bounds, hn[(size_t)ref].child[1], me);
-        t[(size_t)me].child[0] = a, t[(size_t)me].child[1] = b;
-        t[(size_t)me].box = merged(t[(size_t)a].box, t[(size_t)b].box);
-        return me;
-    }
-    void measure(int n, int depth) { // depth of every node, height of every subtree
-        N &x = t[(size_t)n];
-        x.depth = depth;
-        x.height = 0;
-        if (x.prim >= 0) return;
-        measure(x.child[0], depth + 1);
-        measure(x.child[1], depth + 1);
-        x.height = 1 + std::max(t[(size_t)x.child[0]].height, t[(size_t)x.child[1]].height);
-    }
-    void refit_from(int n) {
-        for (; n >= 0; n = t[(size_t)n].parent) t[(size_t)n].box = merged(t[(size_t)t[(size_t)n].child[0]].box, t[(size_t)t[(size_t)n].child[1]].box);
-    }
-    double inner_area() const {
-        double a = 0.0;
-        for (const N &x : t)
-            if (x.prim < 0 && x.parent != -2) a += area(x.box);
-        return a;
-    }
-    // best place for subtree `n` (detached, height h): the node X that minimises area(X u n) + the growth of X's ancestors
-    void search(int x, double induced, const Aabb &nb, int h, double *best, int *best_x) const {
-        const N &X = t[(size_t)x];
-        const double direct = area(merged(X.box, nb));
-        // the new parent sits at X's depth; X's subtree and n's move one level down
-        if (induced + direct < *best && X.depth + 1 + std::max(X.height, h) <= depth_limit) {
-            *best = induced + direct;
-            *best_x = x;
-        }
-        if (X.prim >= 0) return;
-        const double below = induced + direct - area(X.box); // what X itself grows by if n goes somewhere under it
-        if (below + area(nb) >= *best) return;                // even a perfect fit further down cannot win
-        search(X.child[0], below, nb, h, best, best_x);
-        search(X.child[1], below, nb, h, best, best_x);
-    }
-    bool reinsert(int n) {
-        const int p = t[(size_t)n].parent;
-        if (p < 0 || t[(size_t)p].parent < 0) return false; // the root and its children stay
-        const int g = t[(size_t)p].parent, s = t[(size_t)p].child[0] == n ? t[(size_t)p].child[1] : t[(size_t)p].child[0];
-        const double before = inner_area();
-        // detach: the sibling takes the parent's place
-        t[(size_t)g].child[t[(size_t)g].child[0] == p ? 0 : 1] = s;
-        t[(size_t)s].parent = g;
-        t[(size_t)p].parent = -2; // out of the tree
-        refit_from(g);
-        measure(root, 0);
-        double best = kInf;
-        int x = -1;
-        search(root, 0.0, t[(size_t)n].box, t[(size_t)n].height, &best, &x);
-        if (x < 0) x = s; // cannot happen while the limit admits the old place
-        // attach: p becomes the parent of (x, n) where x was
-        const int xp = t[(size_t)x].parent;
-        if (xp >= 0)
-            t[(size_t)xp].child[t[(size_t)xp].child[0] == x ? 0 : 1] = p;
-        else
-            root = p;
-        t[(size_t)p].parent = xp;
-        t[(size_t)p].child[0] = x, t[(size_t)p].child[1] = n;
-        t[(size_t)x].parent = p, t[(size_t)n].parent = p;
-        refit_from(p);
-        return inner_area() < before * (1.0 - 1e-12);
-    }
-    int32_t export_to(std::vector<HostNode> *out, int n, int depth, int *max_depth) const {
-        const N &x = t[(size_t)n];
-        if (x.prim >= 0) {
-            *max_depth = std::max(*max_depth, depth);
-            return ~x.prim;
-        }
-        const int32_t me = (int32_t)out->size();
-        out->emplace_back();
-        const int32_t c0 = export_to(out, x.child[0], depth + 1, max_depth), c1 = export_to(out, x.child[1], depth + 1, max_depth);
-        HostNode &h = (*out)[(size_t)me];
-        h.box[0] = t[(size_t)x.child[0]].box, h.box[1] = t[(size_t)x.child[1]].box;
-        h.child[0] = c0, h.child[1] = c1;
-        return me;
-    }
-};
-
 } // namespace
 
 int32_t build_bvh(const std::vector<Aabb> &bounds, int first, int n, std::vector<HostNode> *nodes, int *max_depth) {
@@ -1111,33 +1003,8 @@ int32_t build_bvh(const std::vector<Aabb> &bounds, int first, int n, std::vector
     for (int i = first; i < n; ++i) ids.push_back(i);
     Builder b{bounds, *nodes};
     Aabb box;
-    int32_t root = b.build(std::move(ids), 0, RT_STACK_DEPTH - 1, &box);
+    const int32_t root = b.build(std::move(ids), 0, RT_STACK_DEPTH - 1, &box);
     *max_depth = b.max_depth;
-    const char *env = std::getenv("RT_BVH_REINSERT");
-    const int passes = env ? std::atoi(env) : 0;
-    const char *env_d = std::getenv("RT_BVH_DEPTH_SLACK");
-    if (passes > 0 && nodes->size() >= 4) {
-        Reinserter r;
-        r.depth_limit = std::min(RT_STACK_DEPTH - 1, b.max_depth + (env_d ? std::atoi(env_d) : 0));
-        r.root = r.import(*nodes, bounds, root, -1);
-        r.measure(r.root, 0);
-        const double a0 = r.inner_area();
-        for (int pass = 0; pass < passes; ++pass) {
-            // largest subtrees first: they cost the most where they sit badly
-            std::vector<int> order;
-            for (int i = 0; i < (int)r.t.size(); ++i)
-                if (i != r.root) order.push_back(i);
-            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return Reinserter::area(r.t[(size_t)x].box) > Reinserter::area(r.t[(size_t)y].box); });
-            int moved = 0;
-            for (int i : order) moved += r.reinsert(i) ? 1 : 0;
-            if (std::getenv("RT_BVH_VERBOSE")) std::fprintf(stderr, "bvh reinsertion pass %d: %d moved, inner area %.4f of the sweep build's\n", pass, moved, r.inner_area() / a0);
-            if (!moved) break;
-        }
-        nodes->clear();
-        int md = 0;
-        root = r.export_to(nodes, r.root, 0, &md);
-        *max_depth = md;
-    }
     return root; // a single prim yields a leaf reference and no nodes
 }
 
