@@ -9,7 +9,50 @@
 // -DRT_EMULATE_DEVICE_MATH liblane_emul_devmath.so takes the DEVICE forms -- the shared-reciprocal divisions, the funnel-shift
 // rotations, the numbers assembled from bits -- with portable stand-ins for the three intrinsics (include/rt_rng.h, rt_lane.h:
 // RTL_RCP64 is a reciprocal deliberately spoilt to v_rcp_f64's documented error bound).  Both have to match the oracle bit for bit.
+// The lane program's libm calls (log in media, sin in the checker texture, atan2 / acos in a sphere's uv) go through recording
+// wrappers -- the only place where the device's results may legitimately differ from the host's (its libm is not correctly
+// rounded, the host's mostly is): tools/libm_attribution.py replays a sample's recorded arguments through the device's functions
+// (tools/microbench/libm_probe.hip) to show which call made a GPU pixel differ.  Macros, so that rt_lane.h stays as it is.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <math.h>
+#include <vector>
+namespace lane_trace {
+struct Call {
+    int sample, fn; // fn: 0 log, 1 sin, 2 atan2, 3 acos
+    double a, b, r;
+};
+static std::vector<Call> *sink = nullptr;
+static int cur_sample = 0;
+static inline double rec(int fn, double a, double b, double r) {
+    if (sink) sink->push_back(Call{cur_sample, fn, a, b, r});
+    return r;
+}
+static int perturb_log = 0; // lane_emul_set_log_perturbation: move log's result by one ulp for about 1 argument in N (a stand-in for a libm that is not correctly rounded)
+static inline double t_log(double x) {
+    double r = ::log(x);
+    if (perturb_log > 0) {
+        uint64_t b;
+        memcpy(&b, &x, sizeof b);
+        b *= 0x9E3779B97F4A7C15ull;
+        if ((b >> 20) % (uint64_t)perturb_log == 0u) r = nextafter(r, (b >> 63) ? 1.0 : -100.0);
+    }
+    return rec(0, x, 0.0, r);
+}
+static inline double t_sin(double x) { return rec(1, x, 0.0, ::sin(x)); }
+static inline double t_atan2(double y, double x) { return rec(2, y, x, ::atan2(y, x)); }
+static inline double t_acos(double x) { return rec(3, x, 0.0, ::acos(x)); }
+} // namespace lane_trace
+#define log(x) lane_trace::t_log(x)
+#define sin(x) lane_trace::t_sin(x)
+#define atan2(y, x) lane_trace::t_atan2(y, x)
+#define acos(x) lane_trace::t_acos(x)
 #include "../ray-tracer_amd/csrc/rt_lane.h"
+#undef log
+#undef sin
+#undef atan2
+#undef acos
 #include "../ray-tracer_amd/csrc/rt_lds.h"
 #include "../ray-tracer_amd/csrc/rt_scene_priv.h"
 #include "../include/rt_mi355x.h"
@@ -53,6 +96,7 @@ void run(const RtLaunch &L, int x0, int y0, int x1, int y1, double *out, double 
         for (int x = x0; x < x1; ++x) {
             rtl::V3 acc = rtl::mk(0, 0, 0);
             for (int s = 0; s < L.spp; ++s) {
+                lane_trace::cur_sample = s;
                 rtl::PathState ps;
                 rtl::Trav tv;
                 rtl::V3 rad = rtl::mk(0, 0, 0);
@@ -274,3 +318,28 @@ extern "C" void lane_emul_rng_forms(long n, const uint64_t *x, uint64_t *rot24, 
         pm1[i] = rt_u64_to_pm1(x[i]);
     }
 }
+
+// The libm calls of one pixel's samples, in program order: renders the pixel alone with the recording on.
+// out: max_calls x {sample, fn, a, b, host result}; returns the number of calls (may exceed max_calls: then only the first are stored)
+extern "C" long lane_emul_trace_pixel(rt_scene *s, const rt_camera *cam, int W, int H, int spp, int max_depth, uint64_t seed, int x, int y,
+                                      double *out, long max_calls) {
+    std::vector<lane_trace::Call> calls;
+    std::vector<double> img((size_t)W * (size_t)H * 3);
+    unsigned long long cnt[5];
+    int hw = 0;
+    lane_trace::sink = &calls;
+    const int rc = lane_emul_render(s, cam, W, H, spp, max_depth, seed, x, y, x + 1, y + 1, img.data(), nullptr, -1, -1, cnt, &hw);
+    lane_trace::sink = nullptr;
+    if (rc != 0) return -1;
+    for (long i = 0; i < (long)calls.size() && i < max_calls; ++i) {
+        out[5 * i + 0] = (double)calls[(size_t)i].sample;
+        out[5 * i + 1] = (double)calls[(size_t)i].fn;
+        out[5 * i + 2] = calls[(size_t)i].a;
+        out[5 * i + 3] = calls[(size_t)i].b;
+        out[5 * i + 4] = calls[(size_t)i].r;
+    }
+    return (long)calls.size();
+}
+
+// sensitivity probe: log's result off by one ulp for about one argument in n (0: never) -- what a device libm does to an image
+extern "C" void lane_emul_set_log_perturbation(int one_in_n) { lane_trace::perturb_log = one_in_n; }

@@ -75,6 +75,16 @@ def load(name):
     _LIB.lane_emul_device_math.restype = C.c_int
     _LIB.lane_emul_set_rcp_mode.argtypes = [C.c_int]
     _LIB.lane_emul_rcp_calls.restype = C.c_ulonglong
+    _LIB.lane_emul_set_log_perturbation.argtypes = [C.c_int]
+    _LIB.lane_emul_trace_pixel.restype = C.c_long
+    _LIB.lane_emul_trace_pixel.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, _DP, C.c_long]
+
+    def trace_pixel(scene, cam, W, H, spp, max_depth, seed, x, y, max_calls=1 << 16):
+        """the lane program's libm calls for pixel (x, y), in program order -> (n, 5) array of {sample, fn (0 log, 1 sin, 2 atan2, 3 acos), a, b, host result}"""
+        out = np.zeros((max_calls, 5))
+        n = _LIB.lane_emul_trace_pixel(scene._h, C.addressof(cam.c), W, H, spp, max_depth, seed, x, y, out.ctypes.data_as(_DP), max_calls)
+        assert 0 <= n <= max_calls, n
+        return out[:n]
     _LIB.lane_emul_div3.argtypes = [C.c_long, _DP, _DP, _DP]
     _LIB.lane_emul_sphere_roots.argtypes = [C.c_long, _DP, _DP, _DP, _DP]
     _LIB.lane_emul_sphere_t_world.argtypes = [C.c_long, _DP, _DP, _DP, _DP]
@@ -113,7 +123,7 @@ def load(name):
     ns = types.SimpleNamespace(render=render, ball_check=ball_check, medium_forms=medium_forms, lds_layout=lds_layout, div3=div3,
                                sphere_roots=sphere_roots, sphere_t_world=sphere_t_world, rng_forms=rng_forms,
                                device_math=bool(_LIB.lane_emul_device_math()), set_rcp_mode=_LIB.lane_emul_set_rcp_mode,
-                               rcp_calls=lambda: int(_LIB.lane_emul_rcp_calls()), name=name)
+                               rcp_calls=lambda: int(_LIB.lane_emul_rcp_calls()), trace_pixel=trace_pixel, set_log_perturbation=_LIB.lane_emul_set_log_perturbation, name=name)
     return ns
 
 

@@ -141,3 +141,31 @@ def test_scenes_with_device_arithmetic_match_the_oracle(scenes, oracle, lane_dev
     assert lane_devmath.rcp_calls() - before > cnt["segments"], name  # at least the segment's reciprocal and one normalisation each
     assert np.array_equal(img, ref), name
     assert cnt["segments"] == ocnt["segments"], name
+
+
+def test_libm_calls_of_a_pixel_are_recorded(scenes, lane_emul):
+    """The hooks tools/libm_attribution.py stands on: the harness records the arguments its lane program passes to log / sin /
+    atan2 / acos (the only functions whose device results may differ from the host's), and can move every log by an ulp to
+    show how little of that reaches a picture."""
+    sc, cam = scenes.build_product(scenes.cover(1, 1.0), device=-1)
+    W = H = 48
+    calls = np.concatenate([lane_emul.trace_pixel(sc, cam, W, H, 3, 50, 5, x, y) for x, y in ((30, 20), (24, 24), (10, 40), (36, 12))])
+    fns = set(int(f) for f in calls[:, 1])
+    assert 0 in fns  # the fog: one keyed free-flight draw per segment at least
+    import math  # the C library's functions (numpy's vectorised ones are another implementation, an ulp apart here and there)
+    for f, host in ((0, math.log), (1, math.sin), (3, math.acos)):
+        c = calls[calls[:, 1] == f]
+        assert same_bits(c[:, 4], [host(v) for v in c[:, 2]])
+    c = calls[calls[:, 1] == 2]
+    assert same_bits(c[:, 4], [math.atan2(a, b) for a, b in c[:, 2:4]])
+    assert np.all((calls[calls[:, 1] == 0][:, 2] > 0.0) & (calls[calls[:, 1] == 0][:, 2] < 1.0))  # log of a uniform draw
+    base, *_ = lane_emul.render(sc, cam, W, H, 2, 50, 5)
+    try:
+        lane_emul.set_log_perturbation(1)
+        moved, *_ = lane_emul.render(sc, cam, W, H, 2, 50, 5)
+    finally:
+        lane_emul.set_log_perturbation(0)
+    again, *_ = lane_emul.render(sc, cam, W, H, 2, 50, 5)
+    assert np.array_equal(base, again)
+    changed = np.abs(moved - base).max(axis=2) > 0.0
+    assert changed.mean() < 0.5 and np.abs(moved - base).mean() <= 1e-4  # an ulp in every free flight stays far inside the stated bar
