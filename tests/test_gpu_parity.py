@@ -795,6 +795,38 @@ def test_deferred_output_overlaps_renders_and_changes_nothing(rt, scenes, gpu_de
     assert np.array_equal(imgs[0].cpu().numpy().reshape(H, W, 3), want[0])
 
 
+def test_concurrent_renders_from_host_threads(rt, scenes, gpu_device):
+    """SURVEY.md section 8(b), threading: `rt_render` is callable concurrently on a committed scene (the reference's scene is
+    `Send + Sync` and every thread renders from it, examples/book-one.rs:52-88).  Four host threads render different jobs from
+    ONE scene and from a clone of it at the same time (ctypes releases the GIL); every image equals the one rendered alone."""
+    import threading
+    sc, cam = scenes.build_product(scenes.book_one(1, 1.5), device=gpu_device)
+    clone = sc.clone(gpu_device)
+    jobs = [(96, 64, 6, 50, 1), (60, 40, 9, 20, 2), (120, 80, 3, 100, 3), (48, 32, 12, 7, 4)]
+    alone = [sc.render(cam, W, H, spp, depth, seed=seed) for W, H, spp, depth, seed in jobs]
+    got, errors = {}, []
+
+    def work(tid):
+        try:
+            for rep in range(3):
+                k = (tid + rep) % len(jobs)
+                W, H, spp, depth, seed = jobs[k]
+                got[(tid, rep)] = (k, (clone if tid % 2 else sc).render(cam, W, H, spp, depth, seed=seed))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors and len(got) == 12, errors
+    for (tid, rep), (k, img) in got.items():
+        assert np.array_equal(img, alone[k]), (tid, rep, k)
+    sc.status()
+    clone.status()
+
+
 def test_bench_two_ranks_rehearsal(gpu_device):
     """bench.py's N > 1 path end to end on this one-GPU box: two processes (torch.distributed.run, gloo, both on cuda:0) render
     their tile shards with the HIP kernel, gather, un-permute; rank 0 reports each rank's step anatomy and checks the
