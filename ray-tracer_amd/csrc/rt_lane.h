@@ -783,6 +783,32 @@ RT_HD void trav_pop(Trav &tv, Stack &st) {
     }
 }
 
+RT_HD uint32_t hi_word(double x) {
+#if defined(RT_DEVICE_MATH)
+    return RT_DOUBLE_HI(x);
+#else
+    uint64_t b;
+    memcpy(&b, &x, sizeof b);
+    return (uint32_t)(b >> 32);
+#endif
+}
+// The reference never renormalises a direction that went through a matrix (quirk Q5), and a path that keeps scattering under a
+// non-rigid matrix can multiply |d| by the scale at every bounce: after thirty bounces at 1 / 22 a direction of 1e-38 is an
+// ordinary binary64 ray for the reference's binary64 slabs, but its 1 / d, or o / d, no longer fits binary32 -- inf - inf in the
+// entry planes, and the culling boxes stopped being conservative (found by the 60 000-scene sweep of round 3: one sample of one
+// scene lost its medium at the 35th bounce).  A segment whose d.d leaves [2^-100, 2^101) therefore walks WITHOUT culling:
+// constants with which every box is "hit" from t = 0 to the best hit so far, so that the binary64 tests see every prim (slow,
+// correct, and only ever for directions no renderer produces on purpose).  Nothing changes for any other segment.
+RT_HD bool cull_range_left(double a) { return ((hi_word(a) >> 20) & 0x7FFu) - 923u > 200u; } // a = d.d; also zero, denormal, inf, NaN
+RT_HD void trav_no_culling(const RtLaunch &L, Trav &tv) {
+    tv.idx = tv.idy = tv.idz = 0.0f;
+    tv.nx = tv.ny = tv.nz = -__builtin_huge_valf(); // entry: max(-inf, 0) = 0
+    tv.fx = tv.fy = tv.fz = __builtin_huge_valf();  // exit: min(+inf, best) = best
+    tv.ox = 0u;
+    tv.oy = L.n_list ? 12u : 8u;
+    tv.oz = L.n_list ? 24u : 16u;
+}
+
 // binary32 constants of a segment's ray (what a traversal needs besides o, d and the best hit so far)
 RT_HD void trav_ray_constants(const RtLaunch &L, V3 o, V3 d, Trav &tv) {
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
@@ -817,6 +843,8 @@ RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack
     const double a = dot(d, d);
     tv.r2a = world_roots_rcp(L, o, a);
     sc.r2a = tv.r2a;
+    // (the segment's shared reciprocal exists exactly when d.d -- and more -- is in range: the range is looked at only without it)
+    if (!(tv.r2a == tv.r2a) && cull_range_left(a)) trav_no_culling(L, tv);
     for (int32_t pi = 0; pi < L.n_hoisted; ++pi) {
         Rec r;
         if (prim_hit<GENERAL, MEDIUM, false>(L, (uint32_t)pi, o, d, a, sc, &r, false)) {

@@ -67,6 +67,13 @@ unsigned long long rtl_emul_rcp_calls = 0;
 #endif
 
 namespace {
+struct Probe { // lane_emul_world_hit
+    bool on = false;
+    rtl::V3 o, d;
+    uint64_t base = 0;
+    double t = 0.0;
+    uint32_t prim = 0;
+} g_probe;
 // the LDS stacks of rt_kernels.hip in host memory: the 16-bit form truncates tnear exactly as the device does
 template <class R>
 struct ArrayStack {
@@ -92,6 +99,33 @@ template <bool G, int M, bool T, bool LENS, class R = RtRef16>
 void run(const RtLaunch &L, int x0, int y0, int x1, int y1, double *out, double *samples_out, int sx, int sy,
          unsigned long long *cnt, int *stack_high) {
     ArrayStack<R> st;
+    if (g_probe.on) { // lane_emul_world_hit: one given ray through begin_segment and the walk, nothing shaded
+        rtl::PathState ps;
+        rtl::Trav tv;
+        ps.o = g_probe.o;
+        ps.d = g_probe.d;
+        ps.T = rtl::mk(1.0, 1.0, 1.0);
+        ps.k = 0;
+        ps.g.base = g_probe.base;
+        rt_rng_seed_state(ps.g.base, &ps.g.s0, &ps.g.s1);
+        ps.g.draws = 0;
+        rtl::begin_segment<G, M, T>(L, &ps, tv, st, &cnt[3]);
+        while (tv.cur != R::kDone) {
+            if (tv.cur < R::kLeaf) {
+                if (L.n_list)
+                    rtl::trav_list_step(reinterpret_cast<const float *>(L.nodes), (uint32_t)L.n_list, (uint32_t)L.n_hoisted, tv, st);
+                else
+                    rtl::trav_node_step(L.nodes, tv, st);
+                cnt[2]++;
+            } else {
+                rtl::leaf_step<G, M, T>(L, &ps, tv, st, &cnt[3]);
+            }
+        }
+        g_probe.t = tv.best_t;
+        g_probe.prim = tv.best_prim;
+        *stack_high = st.high_water;
+        return;
+    }
     for (int y = y0; y < y1; ++y)
         for (int x = x0; x < x1; ++x) {
             rtl::V3 acc = rtl::mk(0, 0, 0);
@@ -343,3 +377,22 @@ extern "C" long lane_emul_trace_pixel(rt_scene *s, const rt_camera *cam, int W, 
 
 // sensitivity probe: log's result off by one ulp for about one argument in n (0: never) -- what a device libm does to an image
 extern "C" void lane_emul_set_log_perturbation(int one_in_n) { lane_trace::perturb_log = one_in_n; }
+
+// World::hit for one given ray as the lane program finds it (hoisted prims, binary32 culling, binary64 tests; keyed medium draws
+// of stream (seed, stream), segment 0): out = {t, prim}; returns 1 for a hit.  The oracle's counterpart is orc_kat_world_hit.
+extern "C" int lane_emul_world_hit(rt_scene *s, const rt_camera *cam, const double o[3], const double d[3], uint64_t seed, uint64_t stream,
+                                   double out[2]) {
+    g_probe.on = true;
+    g_probe.o = rtl::mk(o[0], o[1], o[2]);
+    g_probe.d = rtl::mk(d[0], d[1], d[2]);
+    g_probe.base = rt_rng_base(seed, stream);
+    double img[3] = {0, 0, 0};
+    unsigned long long cnt[5];
+    int hw = 0;
+    const int rc = lane_emul_render(s, cam, 1, 1, 1, 1, seed, 0, 0, 1, 1, img, nullptr, -1, -1, cnt, &hw);
+    g_probe.on = false;
+    if (rc != 0) return -1;
+    out[0] = g_probe.t;
+    out[1] = (double)g_probe.prim;
+    return g_probe.prim != 0xFFFFFFFFu ? 1 : 0;
+}

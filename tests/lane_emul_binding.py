@@ -75,6 +75,15 @@ def load(name):
     _LIB.lane_emul_device_math.restype = C.c_int
     _LIB.lane_emul_set_rcp_mode.argtypes = [C.c_int]
     _LIB.lane_emul_rcp_calls.restype = C.c_ulonglong
+    _LIB.lane_emul_world_hit.restype = C.c_int
+    _LIB.lane_emul_world_hit.argtypes = [C.c_void_p, C.c_void_p, _DP, _DP, C.c_uint64, C.c_uint64, _DP]
+
+    def world_hit(scene, cam, o, d, seed=1, stream=0):
+        """the nearest hit of the ray o + t d as the lane program finds it -> (t, prim) or None"""
+        o, d, out = _d(o), _d(d), np.zeros(2)
+        rc = _LIB.lane_emul_world_hit(scene._h, C.addressof(cam.c), o.ctypes.data_as(_DP), d.ctypes.data_as(_DP), seed, stream, out.ctypes.data_as(_DP))
+        assert rc >= 0
+        return (float(out[0]), int(out[1])) if rc else None
     _LIB.lane_emul_set_log_perturbation.argtypes = [C.c_int]
     _LIB.lane_emul_trace_pixel.restype = C.c_long
     _LIB.lane_emul_trace_pixel.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, _DP, C.c_long]
@@ -123,7 +132,7 @@ def load(name):
     ns = types.SimpleNamespace(render=render, ball_check=ball_check, medium_forms=medium_forms, lds_layout=lds_layout, div3=div3,
                                sphere_roots=sphere_roots, sphere_t_world=sphere_t_world, rng_forms=rng_forms,
                                device_math=bool(_LIB.lane_emul_device_math()), set_rcp_mode=_LIB.lane_emul_set_rcp_mode,
-                               rcp_calls=lambda: int(_LIB.lane_emul_rcp_calls()), trace_pixel=trace_pixel, set_log_perturbation=_LIB.lane_emul_set_log_perturbation, name=name)
+                               rcp_calls=lambda: int(_LIB.lane_emul_rcp_calls()), trace_pixel=trace_pixel, world_hit=world_hit, set_log_perturbation=_LIB.lane_emul_set_log_perturbation, name=name)
     return ns
 
 

@@ -795,6 +795,18 @@ def test_deferred_output_overlaps_renders_and_changes_nothing(rt, scenes, gpu_de
     assert np.array_equal(imgs[0].cpu().numpy().reshape(H, W, 3), want[0])
 
 
+def test_sweep_scene_78971_on_the_gpu(rt, scenes, oracle, gpu_device):
+    """the scene of the 60 000-scene sweep whose 35-bounce path inside a scaled medium lost the medium at |d| = 1e-38"""
+    from test_random_scenes import random_scene_r3
+    seed, W, H, spp = 78971, 60, 53, 2
+    desc = random_scene_r3(scenes, seed)
+    sc, cam = scenes.build_product(desc, device=gpu_device)
+    img = sc.render(cam, W, H, spp, 40, seed=seed)
+    ref = oracle.build_oracle(desc, bvh_seed=seed).render(W, H, spp, 40, seed=seed, iterative=True, nthreads=8)
+    assert np.array_equal(img[18, 23], ref[18, 23])
+    _close(img, ref, max_bad=2)
+
+
 def test_concurrent_renders_from_host_threads(rt, scenes, gpu_device):
     """SURVEY.md section 8(b), threading: `rt_render` is callable concurrently on a committed scene (the reference's scene is
     `Send + Sync` and every thread renders from it, examples/book-one.rs:52-88).  Four host threads render different jobs from

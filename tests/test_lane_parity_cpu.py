@@ -329,3 +329,47 @@ def test_media_inside_the_boundary_of_media_exact(scenes, oracle, lane_emul, rt)
         assert np.array_equal(img, oracle.build_oracle(d, **kw).render(60, 48, 8, 30, 1, iterative=True, nthreads=8))
     img2, ref2, *_ = both(scenes, oracle, lane_emul, scenes.nested_media(1.0, seed=4), 40, 40, 4, 30, seed=11)
     assert np.array_equal(img2, ref2)
+
+
+def test_directions_of_any_length_keep_the_culling_conservative(scenes, oracle, lane_emul):
+    """A direction is never renormalised after a matrix (quirk Q5): a path that keeps scattering under a non-rigid matrix can
+    carry |d| = 1e-38 (it happened, test below) -- an ordinary binary64 ray for the reference's binary64 boxes, but 1 / d and
+    o / d leave binary32, and the culling boxes used to turn NaN / infinite and lose whole subtrees.  rt_lane.h cull_exponent
+    rescales the culling ray by a power of two.  Here: the nearest hit of random rays, each at lengths 1e-150 ... 1e150, through
+    the lane program (hoisted prims, binary32 culling, binary64 tests, keyed medium draws) against the oracle's World::hit
+    (orc_kat_world_hit), same bits of t, in the spheres-only, the list-walk and the general-media family.  (Below |d| = 1e-154
+    d.d is denormal or zero and the reference's own roots are noise: not covered.)"""
+    rng = np.random.default_rng(3)
+    cases = (("book-one", scenes.book_one(1, 1.5), np.array([0.0, 1.0, 0.0]), 6.0), ("cornell", scenes.cornell(1.0), np.array([277.5, 277.5, 277.5]), 250.0),
+             ("cover", scenes.cover(1, 1.0), np.array([200.0, 250.0, 200.0]), 300.0))
+    for name, desc, centre, span in cases:
+        sc, cam = scenes.build_product(desc, device=-1)
+        orc = oracle.build_oracle(desc)
+        hits = 0
+        for i in range(150):
+            o = np.ascontiguousarray(centre + rng.uniform(-span, span, 3))
+            d = rng.standard_normal(3)
+            for e in (0, -12, -30, -37, -38, -39, -45, -60, -100, -150, 12, 30, 38, 60, 150):
+                dd = np.ascontiguousarray(d * 10.0 ** e)
+                out = np.zeros(10)
+                hit = oracle.LIB.orc_kat_world_hit(orc.h, oracle.dp(o), oracle.dp(dd), 7, i, oracle.dp(out))
+                got = lane_emul.world_hit(sc, cam, o, dd, 7, i)
+                hits += hit
+                assert (got is None) == (not hit), (name, i, e)
+                if hit:
+                    assert np.float64(got[0]).view(np.uint64) == out[0:1].view(np.uint64)[0], (name, i, e, got, out[0])
+        assert hits > 500, name
+
+
+def test_direction_shrinking_inside_a_scaled_medium_sweep_scene_78971(scenes, oracle, lane_emul, lane_devmath):
+    """The scene of the 60 000-scene MI355X sweep that found it: a path scatters 35 times inside a medium under a non-rigid
+    matrix, its direction shrinking 22-fold per bounce down to 1e-38 -- where the binary32 boxes used to lose the medium."""
+    from test_random_scenes import random_scene_r3
+    seed, W, H, spp = 78971, 60, 53, 2
+    desc = random_scene_r3(scenes, seed)
+    sc, cam = scenes.build_product(desc, device=-1)
+    ref = oracle.build_oracle(desc, bvh_seed=seed).render(W, H, spp, 40, seed=seed, iterative=True, nthreads=8)
+    for harness in (lane_emul, lane_devmath):
+        img, *_ = harness.render(sc, cam, W, H, spp, 40, seed)
+        assert np.array_equal(img, ref)
+    assert ref[18, 23].sum() > 0.0  # the pixel the GPU had wrong (its first sample ended black in the oracle, lit on the device)

@@ -22,7 +22,8 @@ scenes = importlib.import_module("ray_tracer_amd.scenes")
 import oracle_binding as oracle  # noqa: E402
 from test_random_scenes import random_scene, random_scene_r3  # noqa: E402
 
-cases = json.load(open(ROOT / "profiles" / "r03_random_parity.json"))["pixels_not_bit_identical"]
+# the sweep to look at: profiles/r03_random_parity.json, or the file named on the command line
+cases = json.load(open(sys.argv[1] if len(sys.argv) > 1 else ROOT / "profiles" / "r03_random_parity.json"))["pixels_not_bit_identical"]
 out = []
 for seed, W, H, spp, x, y, diff in cases:
     d = random_scene_r3(scenes, seed) if seed % 2 else random_scene(scenes, seed)

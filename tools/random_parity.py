@@ -21,12 +21,13 @@ import oracle_binding as oracle  # noqa: E402
 from test_random_scenes import random_scene, random_scene_r3  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+FIRST = int(sys.argv[2]) if len(sys.argv) > 2 else 100  # first scene seed
 threads = min(256, os.cpu_count() or 8)
 t0 = time.time()
 worst_mae, worst_max, exact, bad_pixels, pixels = 0.0, 0.0, 0, 0, 0
 hist = {}
 differing = []  # (seed, W, H, spp, x, y, |diff|) of every pixel that is not bit-identical: candidates for a device-libm branch flip
-for seed in range(100, 100 + N):
+for seed in range(FIRST, FIRST + N):
     # every second scene also carries deep transform chains and media inside the boundary of media (round 3)
     d = random_scene_r3(scenes, seed) if seed % 2 else random_scene(scenes, seed)
     rng = np.random.default_rng(seed)
@@ -46,11 +47,15 @@ for seed in range(100, 100 + N):
     hist[nbad] = hist.get(nbad, 0) + 1
     for yy, xx in zip(*np.nonzero(diff.max(axis=2) > 0.0)):
         differing.append([seed, W, H, spp, int(xx), int(yy), float(diff[yy, xx].max())])
+    if (seed - FIRST) % 1000 == 999:  # a sign of life for long sweeps (gpurun takes seven silent minutes for a hang)
+        (ROOT / "gpurun_out").mkdir(exist_ok=True)
+        (ROOT / "gpurun_out" / "random_parity_progress.txt").write_text(f"{seed - FIRST + 1} of {N} scenes, {exact} bit-identical, {time.time() - t0:.0f} s\n")
+        print(f"[{seed - FIRST + 1} / {N}] bit-identical {exact}", flush=True)
     if not finite or mae > 1e-4:
         print("FAIL seed", seed, W, H, spp, mae, nbad, flush=True)
         sys.exit(1)
-res = {"scenes": N, "of_them_with_deep_chains_and_nested_media": N // 2, "bit_identical_scenes": exact, "pixels": pixels, "pixels_differing_by_more_than_1e-12": bad_pixels,
+res = {"scenes": N, "first_seed": FIRST, "of_them_with_deep_chains_and_nested_media": N // 2, "bit_identical_scenes": exact, "pixels": pixels, "pixels_differing_by_more_than_1e-12": bad_pixels,
        "worst_mean_abs_error": worst_mae, "worst_abs_diff": worst_max, "differing_pixels_per_scene_histogram": {str(k): v for k, v in sorted(hist.items())},
        "pixels_not_bit_identical": differing, "seconds": time.time() - t0, "bar": "mean abs error <= 1e-4 per scene"}
 print(res)
-json.dump(res, open(ROOT / "gpurun_out" / "random_parity.json", "w"), indent=1)
+json.dump(res, open(ROOT / "gpurun_out" / ("random_parity.json" if FIRST == 100 else f"random_parity_from_{FIRST}.json"), "w"), indent=1)
