@@ -53,8 +53,8 @@ BASELINE_CONFIGS = {("book_one", 1200, 800, 500): "configs[1]", ("cornell", 600,
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--width", type=int, default=1200)
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--spp", type=int, default=500)
