@@ -783,38 +783,26 @@ RT_HD void trav_pop(Trav &tv, Stack &st) {
     }
 }
 
-RT_HD uint32_t hi_word(double x) {
-#if defined(RT_DEVICE_MATH)
-    return RT_DOUBLE_HI(x);
-#else
-    uint64_t b;
-    memcpy(&b, &x, sizeof b);
-    return (uint32_t)(b >> 32);
-#endif
-}
-// The reference never renormalises a direction that went through a matrix (quirk Q5), and a path that keeps scattering under a
-// non-rigid matrix can multiply |d| by the scale at every bounce: after thirty bounces at 1 / 22 a direction of 1e-38 is an
-// ordinary binary64 ray for the reference's binary64 slabs, but its 1 / d, or o / d, no longer fits binary32 -- inf - inf in the
-// entry planes, and the culling boxes stopped being conservative (found by the 60 000-scene sweep of round 3: one sample of one
-// scene lost its medium at the 35th bounce).  A segment whose d.d leaves [2^-100, 2^101) therefore walks WITHOUT culling:
-// constants with which every box is "hit" from t = 0 to the best hit so far, so that the binary64 tests see every prim (slow,
-// correct, and only ever for directions no renderer produces on purpose).  Nothing changes for any other segment.
-RT_HD bool cull_range_left(double a) { return ((hi_word(a) >> 20) & 0x7FFu) - 923u > 200u; } // a = d.d; also zero, denormal, inf, NaN
-RT_HD void trav_no_culling(const RtLaunch &L, Trav &tv) {
-    tv.idx = tv.idy = tv.idz = 0.0f;
-    tv.nx = tv.ny = tv.nz = -__builtin_huge_valf(); // entry: max(-inf, 0) = 0
-    tv.fx = tv.fy = tv.fz = __builtin_huge_valf();  // exit: min(+inf, best) = best
-    tv.ox = 0u;
-    tv.oy = L.n_list ? 12u : 8u;
-    tv.oz = L.n_list ? 24u : 16u;
-}
-
+// The reference never renormalises a direction that went through a matrix (quirk Q5) and never looks at its components: a path
+// that keeps scattering under a non-rigid matrix can carry |d| = 1e-38, and one that bounces between two parallel mirrors drives
+// ONE component towards zero, 3-fold per bounce, while |d| stays put -- ordinary binary64 rays for the reference's binary64
+// slabs.  In the binary32 culling boxes 1 / d_i of such a component is finite but o_i / d_i and plane / d_i overflow, separately,
+// to infinities of either sign; their difference came out +inf where the slab holds the whole ray, and the box -- with the
+// mirror, or the medium, in it -- was culled (two scenes of the 60 000- and 50 000-scene sweeps of round 3).  A reciprocal
+// beyond 2^60 is therefore made INFINITE: with it every product of that axis is inf or NaN and the axis drops out of the slab
+// test (the rule the exact zeros of a direction have always followed, see below) -- conservative, and when all three
+// components are that small the segment simply walks without culling.  Nothing changes for any other segment.
 // binary32 constants of a segment's ray (what a traversal needs besides o, d and the best hit so far)
 RT_HD void trav_ray_constants(const RtLaunch &L, V3 o, V3 d, Trav &tv) {
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
     tv.idx = rcp32((float)d.x);
     tv.idy = rcp32((float)d.y);
     tv.idz = rcp32((float)d.z);
+    if (fmaxf(fmaxf(fabsf(tv.idx), fabsf(tv.idy)), fabsf(tv.idz)) > 0x1p60f) { // (hardly ever)
+        if (fabsf(tv.idx) > 0x1p60f) tv.idx = copysignf(__builtin_huge_valf(), tv.idx);
+        if (fabsf(tv.idy) > 0x1p60f) tv.idy = copysignf(__builtin_huge_valf(), tv.idy);
+        if (fabsf(tv.idz) > 0x1p60f) tv.idz = copysignf(__builtin_huge_valf(), tv.idz);
+    }
     // the binary32 ray is displaced from the binary64 one by <= 2^-24 (|o| + t|d|) per axis;
     // the box pad covers the |o + t d| share, this pad the |o| share (>2x margin each)
     const float e = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) * 0x1p-21f + 1e-30f;
@@ -843,8 +831,6 @@ RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack
     const double a = dot(d, d);
     tv.r2a = world_roots_rcp(L, o, a);
     sc.r2a = tv.r2a;
-    // (the segment's shared reciprocal exists exactly when d.d -- and more -- is in range: the range is looked at only without it)
-    if (!(tv.r2a == tv.r2a) && cull_range_left(a)) trav_no_culling(L, tv);
     for (int32_t pi = 0; pi < L.n_hoisted; ++pi) {
         Rec r;
         if (prim_hit<GENERAL, MEDIUM, false>(L, (uint32_t)pi, o, d, a, sc, &r, false)) {

@@ -807,6 +807,18 @@ def test_sweep_scene_78971_on_the_gpu(rt, scenes, oracle, gpu_device):
     _close(img, ref, max_bad=2)
 
 
+def test_sweep_scene_115102_on_the_gpu(rt, scenes, oracle, gpu_device):
+    """the scene of the depth-100 sweep whose ray between two parallel mirrors lost one component to 1e-38 (and with it the mirror)"""
+    from test_random_scenes import random_scene
+    seed, W, H, spp = 115102, 78, 53, 2
+    desc = random_scene(scenes, seed)
+    sc, cam = scenes.build_product(desc, device=gpu_device)
+    img = sc.render(cam, W, H, spp, 100, seed=seed)
+    ref = oracle.build_oracle(desc, bvh_seed=seed).render(W, H, spp, 100, seed=seed, iterative=True, nthreads=8)
+    _close(img, ref, max_bad=2)
+    assert np.array_equal(img[0:5, 37], ref[0:5, 37])
+
+
 def test_concurrent_renders_from_host_threads(rt, scenes, gpu_device):
     """SURVEY.md section 8(b), threading: `rt_render` is callable concurrently on a committed scene (the reference's scene is
     `Send + Sync` and every thread renders from it, examples/book-one.rs:52-88).  Four host threads render different jobs from

@@ -334,8 +334,9 @@ def test_media_inside_the_boundary_of_media_exact(scenes, oracle, lane_emul, rt)
 def test_directions_of_any_length_keep_the_culling_conservative(scenes, oracle, lane_emul):
     """A direction is never renormalised after a matrix (quirk Q5): a path that keeps scattering under a non-rigid matrix can
     carry |d| = 1e-38 (it happened, test below) -- an ordinary binary64 ray for the reference's binary64 boxes, but 1 / d and
-    o / d leave binary32, and the culling boxes used to turn NaN / infinite and lose whole subtrees.  rt_lane.h cull_exponent
-    rescales the culling ray by a power of two.  Here: the nearest hit of random rays, each at lengths 1e-150 ... 1e150, through
+    o / d leave binary32, and the culling boxes used to turn NaN / infinite and lose whole subtrees.  rt_lane.h trav_ray_constants
+    makes such a reciprocal infinite, which drops the axis.  Here: the nearest hit of random rays, each at lengths 1e-150 ... 1e150
+    and with single components scaled down to 1e-300 (a ray between two parallel mirrors loses one component bounce by bounce), through
     the lane program (hoisted prims, binary32 culling, binary64 tests, keyed medium draws) against the oracle's World::hit
     (orc_kat_world_hit), same bits of t, in the spheres-only, the list-walk and the general-media family.  (Below |d| = 1e-154
     d.d is denormal or zero and the reference's own roots are noise: not covered.)"""
@@ -346,11 +347,19 @@ def test_directions_of_any_length_keep_the_culling_conservative(scenes, oracle, 
         sc, cam = scenes.build_product(desc, device=-1)
         orc = oracle.build_oracle(desc)
         hits = 0
-        for i in range(150):
+        for i in range(60):
             o = np.ascontiguousarray(centre + rng.uniform(-span, span, 3))
             d = rng.standard_normal(3)
-            for e in (0, -12, -30, -37, -38, -39, -45, -60, -100, -150, 12, 30, 38, 60, 150):
-                dd = np.ascontiguousarray(d * 10.0 ** e)
+            variants = [d * 10.0 ** e for e in (0, -12, -30, -37, -38, -39, -45, -60, -100, -150, 12, 30, 38, 60, 150)]
+            # ONE component (or two) sinking towards zero while |d| stays put: the ray between two parallel mirrors
+            for e in (-17, -19, -30, -38, -42, -46, -100, -300):
+                for axes in ((0,), (1,), (2,), (0, 1), (1, 2)):
+                    v = d.copy()
+                    v[list(axes)] *= 10.0 ** e
+                    variants.append(v)
+            for dd in variants:
+                e = dd
+                dd = np.ascontiguousarray(dd)
                 out = np.zeros(10)
                 hit = oracle.LIB.orc_kat_world_hit(orc.h, oracle.dp(o), oracle.dp(dd), 7, i, oracle.dp(out))
                 got = lane_emul.world_hit(sc, cam, o, dd, 7, i)
@@ -373,3 +382,17 @@ def test_direction_shrinking_inside_a_scaled_medium_sweep_scene_78971(scenes, or
         img, *_ = harness.render(sc, cam, W, H, spp, 40, seed)
         assert np.array_equal(img, ref)
     assert ref[18, 23].sum() > 0.0  # the pixel the GPU had wrong (its first sample ended black in the oracle, lit on the device)
+
+
+def test_component_sinking_between_parallel_mirrors_sweep_scene_115102(scenes, oracle, lane_emul):
+    """The scene of the 50 000-scene depth-100 sweep: a ray caught between two parallel mirrors keeps |d| while one component
+    sinks 3-fold per bounce, to 1e-38 at the 86th -- there o_y / d_y overflowed binary32, the mirror's box was culled and the path
+    escaped to the light (oracle: black after 100 bounces)."""
+    from test_random_scenes import random_scene
+    seed, W, H, spp = 115102, 78, 53, 2
+    desc = random_scene(scenes, seed)
+    sc, cam = scenes.build_product(desc, device=-1)
+    ref = oracle.build_oracle(desc, bvh_seed=seed).render(W, H, spp, 100, seed=seed, iterative=True, nthreads=8)
+    img, *_ = lane_emul.render(sc, cam, W, H, spp, 100, seed)
+    assert np.array_equal(img, ref)
+    assert ref[0, 37].sum() == 0.0  # the pixel the GPU had lit

@@ -23,25 +23,26 @@ import oracle_binding as oracle  # noqa: E402
 from test_random_scenes import random_scene, random_scene_r3  # noqa: E402
 
 # the sweep to look at: profiles/r03_random_parity.json, or the file named on the command line
-cases = json.load(open(sys.argv[1] if len(sys.argv) > 1 else ROOT / "profiles" / "r03_random_parity.json"))["pixels_not_bit_identical"]
+sweep = json.load(open(sys.argv[1] if len(sys.argv) > 1 else ROOT / "profiles" / "r03_random_parity.json"))
+cases, DEPTH = sweep["pixels_not_bit_identical"], int(sweep.get("max_depth", 40))
 out = []
 for seed, W, H, spp, x, y, diff in cases:
     d = random_scene_r3(scenes, seed) if seed % 2 else random_scene(scenes, seed)
     orc = oracle.build_oracle(d, bvh_seed=seed)
-    want = orc.pixel_samples(W, H, spp, 40, seed, x, y, iterative=True)
-    res = {"seed": seed, "W": W, "H": H, "spp": spp, "x": x, "y": y}
+    want = orc.pixel_samples(W, H, spp, DEPTH, seed, x, y, iterative=True)
+    res = {"seed": seed, "W": W, "H": H, "spp": spp, "x": x, "y": y, "max_depth": DEPTH}
     for form in ("timed", "counting", "no_swap"):
         os.environ["RT_SWAP"] = "0" if form == "no_swap" else "1"
         sc, cam = scenes.build_product(d, device=0)
         if form == "counting":
-            img, _ = sc.render(cam, W, H, spp, 40, seed=seed, counters=True)
+            img, _ = sc.render(cam, W, H, spp, DEPTH, seed=seed, counters=True)
         else:
-            img = sc.render(cam, W, H, spp, 40, seed=seed)
+            img = sc.render(cam, W, H, spp, DEPTH, seed=seed)
         res[form + "_pixel"] = img[y, x].tolist()
         if form == "timed":
             sums, prev, got = np.zeros((H, W, 3)), np.zeros(3), []
             for s in range(spp):  # one sample per pass: the running sum's increments are the samples (exact while the sums are small)
-                sc.render_progressive(cam, W, H, spp, 40, seed, s, s + 1, sums)
+                sc.render_progressive(cam, W, H, spp, DEPTH, seed, s, s + 1, sums)
                 got.append((sums[y, x] - prev).tolist())
                 prev = sums[y, x].copy()
             got = np.array(got)

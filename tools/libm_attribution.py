@@ -53,7 +53,7 @@ for c in json.load(open(probe)):
     seed, W, H, spp, x, y = (c[k] for k in ("seed", "W", "H", "spp", "x", "y"))
     d = random_scene_r3(scenes, seed) if seed % 2 else random_scene(scenes, seed)
     sc, cam = scenes.build_product(d, device=-1)
-    t = le.trace_pixel(sc, cam, W, H, spp, 40, seed, x, y)
+    t = le.trace_pixel(sc, cam, W, H, spp, int(c.get("max_depth", 40)), seed, x, y)
     entry = {"seed": seed, "x": x, "y": y, "samples_that_differ": c["samples_that_differ"], "calls_of_the_pixel": len(t)}
     for s in c["samples_that_differ"]:
         calls = t[t[:, 0] == s]
