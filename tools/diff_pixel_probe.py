@@ -24,13 +24,21 @@ from test_random_scenes import random_scene, random_scene_r3  # noqa: E402
 
 # the sweep to look at: profiles/r03_random_parity.json, or the file named on the command line
 sweep = json.load(open(sys.argv[1] if len(sys.argv) > 1 else ROOT / "profiles" / "r03_random_parity.json"))
-cases, DEPTH = sweep["pixels_not_bit_identical"], int(sweep.get("max_depth", 40))
+cases, DEPTH, GEN = sweep["pixels_not_bit_identical"], int(sweep.get("max_depth", 40)), sweep.get("generator", "general")
+
+
+def make_scene(seed, aspect):
+    if GEN == "book_one":
+        return scenes.book_one(seed, aspect)
+    if GEN == "cover":
+        return scenes.cover(seed, aspect)
+    return random_scene_r3(scenes, seed) if seed % 2 else random_scene(scenes, seed)
 out = []
 for seed, W, H, spp, x, y, diff in cases:
-    d = random_scene_r3(scenes, seed) if seed % 2 else random_scene(scenes, seed)
+    d = make_scene(seed, W / H)
     orc = oracle.build_oracle(d, bvh_seed=seed)
     want = orc.pixel_samples(W, H, spp, DEPTH, seed, x, y, iterative=True)
-    res = {"seed": seed, "W": W, "H": H, "spp": spp, "x": x, "y": y, "max_depth": DEPTH}
+    res = {"seed": seed, "W": W, "H": H, "spp": spp, "x": x, "y": y, "max_depth": DEPTH, "generator": GEN}
     for form in ("timed", "counting", "no_swap"):
         os.environ["RT_SWAP"] = "0" if form == "no_swap" else "1"
         sc, cam = scenes.build_product(d, device=0)

@@ -51,7 +51,9 @@ if not probe.exists():
     probe = ROOT / "profiles" / "r03_experiments" / "diff_pixel_probe.json"
 for c in json.load(open(probe)):
     seed, W, H, spp, x, y = (c[k] for k in ("seed", "W", "H", "spp", "x", "y"))
-    d = random_scene_r3(scenes, seed) if seed % 2 else random_scene(scenes, seed)
+    gen = c.get("generator", "general")
+    d = (scenes.book_one(seed, W / H) if gen == "book_one" else scenes.cover(seed, W / H) if gen == "cover" else
+         random_scene_r3(scenes, seed) if seed % 2 else random_scene(scenes, seed))
     sc, cam = scenes.build_product(d, device=-1)
     t = le.trace_pixel(sc, cam, W, H, spp, int(c.get("max_depth", 40)), seed, x, y)
     entry = {"seed": seed, "x": x, "y": y, "samples_that_differ": c["samples_that_differ"], "calls_of_the_pixel": len(t)}

@@ -23,6 +23,15 @@ from test_random_scenes import random_scene, random_scene_r3  # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 FIRST = int(sys.argv[2]) if len(sys.argv) > 2 else 100  # first scene seed
 DEPTH = int(sys.argv[3]) if len(sys.argv) > 3 else 40   # maxDepth of the renders
+GEN = sys.argv[4] if len(sys.argv) > 4 else "general"   # general: tests/test_random_scenes.py; book_one / cover: the example scenes by scene seed
+
+
+def make_scene(seed, aspect):
+    if GEN == "book_one":
+        return scenes.book_one(seed, aspect)
+    if GEN == "cover":
+        return scenes.cover(seed, aspect)
+    return random_scene_r3(scenes, seed) if seed % 2 else random_scene(scenes, seed)
 threads = min(256, os.cpu_count() or 8)
 t0 = time.time()
 worst_mae, worst_max, exact, bad_pixels, pixels = 0.0, 0.0, 0, 0, 0
@@ -30,9 +39,9 @@ hist = {}
 differing = []  # (seed, W, H, spp, x, y, |diff|) of every pixel that is not bit-identical: candidates for a device-libm branch flip
 for seed in range(FIRST, FIRST + N):
     # every second scene also carries deep transform chains and media inside the boundary of media (round 3)
-    d = random_scene_r3(scenes, seed) if seed % 2 else random_scene(scenes, seed)
     rng = np.random.default_rng(seed)
     W, H, spp = int(rng.integers(24, 96)), int(rng.integers(16, 72)), int(rng.integers(2, 12))
+    d = make_scene(seed, W / H)
     sc, cam = scenes.build_product(d, device=0)
     img = sc.render(cam, W, H, spp, DEPTH, seed=seed)
     ref = oracle.build_oracle(d, bvh_seed=seed).render(W, H, spp, DEPTH, seed=seed, iterative=True, nthreads=threads)
@@ -55,8 +64,8 @@ for seed in range(FIRST, FIRST + N):
     if not finite or mae > 1e-4:
         print("FAIL seed", seed, W, H, spp, mae, nbad, flush=True)
         sys.exit(1)
-res = {"scenes": N, "first_seed": FIRST, "max_depth": DEPTH, "of_them_with_deep_chains_and_nested_media": N // 2, "bit_identical_scenes": exact, "pixels": pixels, "pixels_differing_by_more_than_1e-12": bad_pixels,
+res = {"scenes": N, "first_seed": FIRST, "max_depth": DEPTH, "generator": GEN, "of_them_with_deep_chains_and_nested_media": N // 2 if GEN == "general" else 0, "bit_identical_scenes": exact, "pixels": pixels, "pixels_differing_by_more_than_1e-12": bad_pixels,
        "worst_mean_abs_error": worst_mae, "worst_abs_diff": worst_max, "differing_pixels_per_scene_histogram": {str(k): v for k, v in sorted(hist.items())},
        "pixels_not_bit_identical": differing, "seconds": time.time() - t0, "bar": "mean abs error <= 1e-4 per scene"}
 print(res)
-json.dump(res, open(ROOT / "gpurun_out" / ("random_parity.json" if (FIRST, DEPTH) == (100, 40) else f"random_parity_from_{FIRST}_depth_{DEPTH}.json"), "w"), indent=1)
+json.dump(res, open(ROOT / "gpurun_out" / ("random_parity.json" if (FIRST, DEPTH, GEN) == (100, 40, "general") else f"random_parity_{GEN}_from_{FIRST}_depth_{DEPTH}.json"), "w"), indent=1)
