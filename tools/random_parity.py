@@ -23,6 +23,7 @@ from test_random_scenes import random_scene, random_scene_r3  # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 FIRST = int(sys.argv[2]) if len(sys.argv) > 2 else 100  # first scene seed
 DEPTH = int(sys.argv[3]) if len(sys.argv) > 3 else 40   # maxDepth of the renders
+SCALE = int(os.environ.get("RANDOM_PARITY_SCALE", "1"))  # image edges and spp times this: many waves, full swap queues
 GEN = sys.argv[4] if len(sys.argv) > 4 else "general"   # general: tests/test_random_scenes.py; book_one / cover: the example scenes by scene seed
 
 
@@ -40,7 +41,7 @@ differing = []  # (seed, W, H, spp, x, y, |diff|) of every pixel that is not bit
 for seed in range(FIRST, FIRST + N):
     # every second scene also carries deep transform chains and media inside the boundary of media (round 3)
     rng = np.random.default_rng(seed)
-    W, H, spp = int(rng.integers(24, 96)), int(rng.integers(16, 72)), int(rng.integers(2, 12))
+    W, H, spp = int(rng.integers(24, 96)) * SCALE, int(rng.integers(16, 72)) * SCALE, int(rng.integers(2, 12)) * SCALE
     d = make_scene(seed, W / H)
     sc, cam = scenes.build_product(d, device=0)
     img = sc.render(cam, W, H, spp, DEPTH, seed=seed)
@@ -57,15 +58,15 @@ for seed in range(FIRST, FIRST + N):
     hist[nbad] = hist.get(nbad, 0) + 1
     for yy, xx in zip(*np.nonzero(diff.max(axis=2) > 0.0)):
         differing.append([seed, W, H, spp, int(xx), int(yy), float(diff[yy, xx].max())])
-    if (seed - FIRST) % 1000 == 999:  # a sign of life for long sweeps (gpurun takes seven silent minutes for a hang)
+    if (seed - FIRST) % (1000 if SCALE == 1 else 20) == (999 if SCALE == 1 else 19):  # a sign of life for long sweeps (gpurun takes seven silent minutes for a hang)
         (ROOT / "gpurun_out").mkdir(exist_ok=True)
         (ROOT / "gpurun_out" / "random_parity_progress.txt").write_text(f"{seed - FIRST + 1} of {N} scenes, {exact} bit-identical, {time.time() - t0:.0f} s\n")
         print(f"[{seed - FIRST + 1} / {N}] bit-identical {exact}", flush=True)
     if not finite or mae > 1e-4:
         print("FAIL seed", seed, W, H, spp, mae, nbad, flush=True)
         sys.exit(1)
-res = {"scenes": N, "first_seed": FIRST, "max_depth": DEPTH, "generator": GEN, "of_them_with_deep_chains_and_nested_media": N // 2 if GEN == "general" else 0, "bit_identical_scenes": exact, "pixels": pixels, "pixels_differing_by_more_than_1e-12": bad_pixels,
+res = {"scenes": N, "first_seed": FIRST, "max_depth": DEPTH, "generator": GEN, "scale": SCALE, "of_them_with_deep_chains_and_nested_media": N // 2 if GEN == "general" else 0, "bit_identical_scenes": exact, "pixels": pixels, "pixels_differing_by_more_than_1e-12": bad_pixels,
        "worst_mean_abs_error": worst_mae, "worst_abs_diff": worst_max, "differing_pixels_per_scene_histogram": {str(k): v for k, v in sorted(hist.items())},
        "pixels_not_bit_identical": differing, "seconds": time.time() - t0, "bar": "mean abs error <= 1e-4 per scene"}
 print(res)
-json.dump(res, open(ROOT / "gpurun_out" / ("random_parity.json" if (FIRST, DEPTH, GEN) == (100, 40, "general") else f"random_parity_{GEN}_from_{FIRST}_depth_{DEPTH}.json"), "w"), indent=1)
+json.dump(res, open(ROOT / "gpurun_out" / ("random_parity.json" if (FIRST, DEPTH, GEN) == (100, 40, "general") else f"random_parity_{GEN}_from_{FIRST}_depth_{DEPTH}" + (f"_x{SCALE}" if SCALE != 1 else "") + ".json"), "w"), indent=1)
