@@ -179,3 +179,33 @@ def test_random_scene_with_deep_chains_and_nested_media_bit_exact(scenes, oracle
     ref, ocnt = oracle.build_oracle(d, bvh_seed=seed).render(32, 24, 3, 40, seed=seed + 100, iterative=True, nthreads=4, counters=True)
     assert np.array_equal(img, ref, equal_nan=True)
     assert cnt["segments"] == ocnt["segments"]
+
+
+def wide_scene(scenes, seed):
+    """more than 32767 leaves (RT_FEAT_WIDE: 32-bit node references, two LDS words per stack entry): a field of ~34 000 spheres,
+    rotated rectangles and cubes with six kinds of material, a ground and an enclosing light"""
+    rng = np.random.default_rng(seed + 4242)
+    d = scenes.SceneDesc()
+    mats = [d.lambertian_rgb(rng.uniform(0.1, 0.9, 3)) for _ in range(3)] + [
+        d.mat("metal", d.tex_solid((0.8, 0.8, 0.8)), float(rng.choice([0.0, 0.2]))), d.mat("dielectric", float(rng.uniform(1.2, 1.8))),
+        d.mat("diffuse_light", d.tex_solid((2.0, 1.6, 1.2)))]
+    sphere = [d.geom("sphere", r) for r in (0.2, 0.3, 0.4)]
+    rect = d.geom("rectangle", 0.7, 0.5)
+    cube = d.geom("cube", 0.5, 0.4, 0.5)
+    n = int(rng.integers(178, 186))
+    for i in range(n):
+        for j in range(n):
+            pos = (i - n / 2 + float(rng.uniform(0, 0.3)), 0.4, j - n / 2 + float(rng.uniform(0, 0.3)))
+            m = mats[int(rng.integers(len(mats)))]
+            k = rng.integers(0, 20)
+            if k < 18:
+                d.sprite(sphere[int(rng.integers(3))], m, scenes.mat4_translation(pos))
+            elif k == 18:
+                d.sprite(rect, m, scenes.mat4_multiplied(scenes.mat4_translation(pos), scenes.mat4_rotation(float(rng.uniform(-2, 2)), (1.0, 0.0, 0.0))))
+            else:
+                d.sprite(cube, m, scenes.mat4_multiplied(scenes.mat4_translation(pos), scenes.mat4_rotation(float(rng.uniform(-1, 1)), (0.0, 1.0, 0.0))))
+    d.sprite(d.geom("sphere", 1000.0), d.lambertian_rgb((0.5, 0.5, 0.5)), scenes.mat4_translation((0.0, -1000.0, 0.0)))
+    d.sprite(d.geom("sphere", 3000.0), d.mat("diffuse_light", d.tex_solid((0.6, 0.7, 1.0))), None)
+    d.camera = ((float(rng.uniform(10, 30)), float(rng.uniform(3, 9)), float(rng.uniform(4, 12))), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 0.5, 1.5, 20.0,
+                float(rng.choice([0.0, 0.02])))
+    return d

@@ -18,7 +18,7 @@ from __graft_entry__ import load_package  # noqa: E402
 rt = load_package()
 scenes = importlib.import_module("ray_tracer_amd.scenes")
 import oracle_binding as oracle  # noqa: E402
-from test_random_scenes import random_scene, random_scene_r3  # noqa: E402
+from test_random_scenes import random_scene, random_scene_r3, wide_scene  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 FIRST = int(sys.argv[2]) if len(sys.argv) > 2 else 100  # first scene seed
@@ -32,6 +32,8 @@ def make_scene(seed, aspect):
         return scenes.book_one(seed, aspect)
     if GEN == "cover":
         return scenes.cover(seed, aspect)
+    if GEN == "wide":
+        return wide_scene(scenes, seed)
     return random_scene_r3(scenes, seed) if seed % 2 else random_scene(scenes, seed)
 threads = min(256, os.cpu_count() or 8)
 t0 = time.time()
@@ -58,7 +60,8 @@ for seed in range(FIRST, FIRST + N):
     hist[nbad] = hist.get(nbad, 0) + 1
     for yy, xx in zip(*np.nonzero(diff.max(axis=2) > 0.0)):
         differing.append([seed, W, H, spp, int(xx), int(yy), float(diff[yy, xx].max())])
-    if (seed - FIRST) % (1000 if SCALE == 1 else 20) == (999 if SCALE == 1 else 19):  # a sign of life for long sweeps (gpurun takes seven silent minutes for a hang)
+    every = 1000 if (SCALE == 1 and GEN != "wide") else 20
+    if (seed - FIRST) % every == every - 1:  # a sign of life for long sweeps (gpurun takes seven silent minutes for a hang)
         (ROOT / "gpurun_out").mkdir(exist_ok=True)
         (ROOT / "gpurun_out" / "random_parity_progress.txt").write_text(f"{seed - FIRST + 1} of {N} scenes, {exact} bit-identical, {time.time() - t0:.0f} s\n")
         print(f"[{seed - FIRST + 1} / {N}] bit-identical {exact}", flush=True)
