@@ -819,6 +819,21 @@ def test_sweep_scene_115102_on_the_gpu(rt, scenes, oracle, gpu_device):
     assert np.array_equal(img[0:5, 37], ref[0:5, 37])
 
 
+def test_degenerate_inputs_on_the_gpu(rt, scenes, oracle, gpu_device):
+    """tests/test_random_scenes.py::degenerate_scenes through the kernels: singular matrices, radii 0 and -1, media of density 0 / -1 /
+    1e300, refractive index 0, fuzz 5, scales 1e-20 and 1e20, a mirrored cube, NaN and infinite translations"""
+    from test_random_scenes import degenerate_scenes
+    for name, d in degenerate_scenes(scenes).items():
+        sc, cam = scenes.build_product(d, device=gpu_device)
+        img = sc.render(cam, 96, 72, 8, 30, seed=5)
+        ref = oracle.build_oracle(d).render(96, 72, 8, 30, seed=5, iterative=True, nthreads=8)
+        both_nan = np.isnan(img) & np.isnan(ref)
+        diff = np.abs(np.where(both_nan, 0.0, img) - np.where(both_nan, 0.0, ref))
+        assert not np.isnan(diff).any(), name
+        assert diff.mean() <= MAE_BAR and int((diff.max(axis=2) > 1e-12).sum()) <= 2, (name, float(diff.max()))
+        sc.close()
+
+
 def test_concurrent_renders_from_host_threads(rt, scenes, gpu_device):
     """SURVEY.md section 8(b), threading: `rt_render` is callable concurrently on a committed scene (the reference's scene is
     `Send + Sync` and every thread renders from it, examples/book-one.rs:52-88).  Four host threads render different jobs from

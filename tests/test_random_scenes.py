@@ -209,3 +209,53 @@ def wide_scene(scenes, seed):
     d.camera = ((float(rng.uniform(10, 30)), float(rng.uniform(3, 9)), float(rng.uniform(4, 12))), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 0.5, 1.5, 20.0,
                 float(rng.choice([0.0, 0.02])))
     return d
+
+
+def degenerate_scenes(scenes):
+    """scenes the builder API accepts although nobody would write them on purpose: what the reference does with them (a sprite under
+    a singular matrix is never hit, src/sprite.rs:131-134; a sphere of radius 0 or -1; a medium of density 0, -1, 1e300; ...) is
+    what the oracle does, and the kernels have to follow -> {name: SceneDesc}"""
+    def base():
+        d = scenes.SceneDesc()
+        d.sprite(d.geom("sphere", 300.0), d.lambertian_rgb((0.5, 0.5, 0.5)), scenes.mat4_translation((0.0, -301.0, 12.0)))
+        d.sprite(d.geom("sphere", 80.0), d.mat("diffuse_light", d.tex_solid((1.0, 0.9, 0.8))), None)
+        d.sprite(d.geom("sphere", 1.0), d.lambertian_rgb((0.8, 0.3, 0.3)), scenes.mat4_translation((0.0, 0.0, 10.0)))
+        d.camera = ((0.0, 0.5, -2.0), (0.0, 0.0, 12.0), (0.0, 1.0, 0.0), 0.9, 4 / 3, 10.0, 0.0)
+        return d
+
+    def scale(x, y, z):
+        m = [0.0] * 16
+        m[0], m[5], m[10], m[15] = x, y, z, 1.0
+        return m
+
+    at = scenes.mat4_translation((2.0, 0.0, 10.0))
+    green = (0.2, 0.8, 0.2)
+    out = {}
+    for name, make in (
+            ("singular matrix", lambda d: d.sprite(d.geom("sphere", 1.0), d.lambertian_rgb(green), scenes.mat4_multiplied(at, scale(1.0, 0.0, 1.0)))),
+            ("radius 0", lambda d: d.sprite(d.geom("sphere", 0.0), d.lambertian_rgb(green), at)),
+            ("radius -1", lambda d: d.sprite(d.geom("sphere", -1.0), d.lambertian_rgb(green), at)),
+            ("rectangle of width 0", lambda d: d.sprite(d.geom("rectangle", 0.0, 2.0), d.lambertian_rgb(green), at)),
+            ("medium of density 0", lambda d: d.sprite(d.geom("medium", d.geom("sphere", 1.5), 0.0), d.mat("isotropic", d.tex_solid((0.5, 0.5, 0.9))), at)),
+            ("medium of density -1", lambda d: d.sprite(d.geom("medium", d.geom("sphere", 1.5), -1.0), d.mat("isotropic", d.tex_solid((0.5, 0.5, 0.9))), at)),
+            ("medium of density 1e300", lambda d: d.sprite(d.geom("medium", d.geom("sphere", 1.5), 1e300), d.mat("isotropic", d.tex_solid((0.5, 0.5, 0.9))), at)),
+            ("refractive index 0", lambda d: d.sprite(d.geom("sphere", 1.0), d.mat("dielectric", 0.0), at)),
+            ("fuzz 5", lambda d: d.sprite(d.geom("sphere", 1.0), d.mat("metal", d.tex_solid((0.9, 0.9, 0.9)), 5.0), at)),
+            ("scale 1e-20", lambda d: d.sprite(d.geom("sphere", 1.0), d.lambertian_rgb(green), scenes.mat4_multiplied(at, scale(1e-20, 1e-20, 1e-20)))),
+            ("scale 1e20", lambda d: d.sprite(d.geom("sphere", 1.0), d.lambertian_rgb(green), scenes.mat4_multiplied(at, scale(1e20, 1e20, 1e20)))),
+            ("mirrored glass cube", lambda d: d.sprite(d.geom("cube", 1.0, 1.0, 1.0), d.mat("dielectric", 1.5), scenes.mat4_multiplied(at, scale(-1.0, 1.0, 1.0)))),
+            ("NaN translation", lambda d: d.sprite(d.geom("sphere", 1.0), d.lambertian_rgb(green), scenes.mat4_translation((float("nan"), 0.0, 10.0)))),
+            ("infinite translation", lambda d: d.sprite(d.geom("sphere", 1.0), d.lambertian_rgb(green), scenes.mat4_translation((float("inf"), 0.0, 10.0))))):
+        d = base()
+        make(d)
+        out[name] = d
+    return out
+
+
+def test_degenerate_inputs_match_the_oracle(scenes, oracle, lane_emul):
+    for name, d in degenerate_scenes(scenes).items():
+        sc, cam = scenes.build_product(d, device=-1)
+        img, cnt, _ = lane_emul.render(sc, cam, 48, 36, 4, 30, 5)
+        ref, ocnt = oracle.build_oracle(d).render(48, 36, 4, 30, 5, iterative=True, nthreads=8, counters=True)
+        assert np.array_equal(img, ref, equal_nan=True), name
+        assert cnt["segments"] == ocnt["segments"], name
