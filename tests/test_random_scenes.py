@@ -259,3 +259,22 @@ def test_degenerate_inputs_match_the_oracle(scenes, oracle, lane_emul):
         ref, ocnt = oracle.build_oracle(d).render(48, 36, 4, 30, 5, iterative=True, nthreads=8, counters=True)
         assert np.array_equal(img, ref, equal_nan=True), name
         assert cnt["segments"] == ocnt["segments"], name
+
+
+def scaled_scene(scenes, seed):
+    """random_scene / random_scene_r3 blown up or shrunk as a whole by K = 10^[-6, 9] (world sprites, camera, focus, lens): the same
+    picture for the reference's binary64 arithmetic, but coordinates of 1e-6 or 1e9 for the binary32 culling boxes and their pads"""
+    d = random_scene_r3(scenes, seed) if seed % 2 else random_scene(scenes, seed)
+    rng = np.random.default_rng(seed + 999)
+    K = float(10.0 ** rng.uniform(-6.0, 9.0))
+    S = [0.0] * 16
+    S[0] = S[5] = S[10] = K
+    S[15] = 1.0
+    owned = set()
+    for g in d.geometries:
+        if g[0] == "bvh":
+            owned.update(g[1])
+    d.sprites = [(g, m, (S if M is None else scenes.mat4_multiplied(S, M)) if i not in owned else M) for i, (g, m, M) in enumerate(d.sprites)]
+    eye, center, up, fov, aspect, focus, lens = d.camera
+    d.camera = (tuple(K * v for v in eye), tuple(K * v for v in center), up, fov, aspect, focus * K, lens * K)
+    return d

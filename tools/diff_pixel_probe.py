@@ -20,7 +20,7 @@ from __graft_entry__ import load_package  # noqa: E402
 rt = load_package()
 scenes = importlib.import_module("ray_tracer_amd.scenes")
 import oracle_binding as oracle  # noqa: E402
-from test_random_scenes import random_scene, random_scene_r3, wide_scene  # noqa: E402
+from test_random_scenes import random_scene, random_scene_r3, scaled_scene, wide_scene  # noqa: E402
 
 # the sweep to look at: profiles/r03_random_parity.json, or the file named on the command line
 sweep = json.load(open(sys.argv[1] if len(sys.argv) > 1 else ROOT / "profiles" / "r03_random_parity.json"))
@@ -34,6 +34,8 @@ def make_scene(seed, aspect):
         return scenes.cover(seed, aspect)
     if GEN == "wide":
         return wide_scene(scenes, seed)
+    if GEN == "scaled":
+        return scaled_scene(scenes, seed)
     return random_scene_r3(scenes, seed) if seed % 2 else random_scene(scenes, seed)
 out = []
 for seed, W, H, spp, x, y, diff in cases:
@@ -62,7 +64,7 @@ for seed, W, H, spp, x, y, diff in cases:
             res["oracle_samples"] = want[bad].tolist()
         sc.close()
     os.environ["RT_SWAP"] = "1"
-    res["oracle_pixel"] = (want.sum(axis=0) / spp).tolist()
+    res["oracle_pixel"] = orc.render(W, H, spp, DEPTH, seed=seed, region=(x, y, x + 1, y + 1), iterative=True)[y, x].tolist()
     res["all_forms_agree"] = res["timed_pixel"] == res["counting_pixel"] == res["no_swap_pixel"]
     print(json.dumps(res), flush=True)
     out.append(res)

@@ -28,7 +28,7 @@ subprocess.run(["make", "-C", str(ROOT / "tests")], check=True, capture_output=T
 rt = load_package()
 scenes = importlib.import_module("ray_tracer_amd.scenes")
 import lane_emul_binding as le  # noqa: E402
-from test_random_scenes import random_scene, random_scene_r3, wide_scene  # noqa: E402
+from test_random_scenes import random_scene, random_scene_r3, scaled_scene, wide_scene  # noqa: E402
 
 NAMES = ("log", "sin", "atan2", "acos")
 
@@ -52,11 +52,16 @@ if not probe.exists():
 for c in json.load(open(probe)):
     seed, W, H, spp, x, y = (c[k] for k in ("seed", "W", "H", "spp", "x", "y"))
     gen = c.get("generator", "general")
-    d = (scenes.book_one(seed, W / H) if gen == "book_one" else scenes.cover(seed, W / H) if gen == "cover" else wide_scene(scenes, seed) if gen == "wide" else
+    d = (scenes.book_one(seed, W / H) if gen == "book_one" else scenes.cover(seed, W / H) if gen == "cover" else wide_scene(scenes, seed) if gen == "wide" else scaled_scene(scenes, seed) if gen == "scaled" else
          random_scene_r3(scenes, seed) if seed % 2 else random_scene(scenes, seed))
     sc, cam = scenes.build_product(d, device=-1)
-    t = le.trace_pixel(sc, cam, W, H, spp, int(c.get("max_depth", 40)), seed, x, y)
+    depth = int(c.get("max_depth", 40))
+    t = le.trace_pixel(sc, cam, W, H, spp, depth, seed, x, y)
     entry = {"seed": seed, "x": x, "y": y, "samples_that_differ": c["samples_that_differ"], "calls_of_the_pixel": len(t)}
+    # does the lane program on the HOST draw the oracle's pixel?  If not, the difference is not the device's (it is the lane program's)
+    import oracle_binding as oracle
+    hp, *_ = le.render(sc, cam, W, H, spp, depth, seed, region=(x, y, x + 1, y + 1))
+    entry["host_harness_equals_oracle"] = bool(np.array_equal(hp[y, x], np.asarray(c["oracle_pixel"])))
     for s in c["samples_that_differ"]:
         calls = t[t[:, 0] == s]
         dev = device(calls[:, 1:4]) if len(calls) else np.zeros(0)

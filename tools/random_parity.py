@@ -18,7 +18,7 @@ from __graft_entry__ import load_package  # noqa: E402
 rt = load_package()
 scenes = importlib.import_module("ray_tracer_amd.scenes")
 import oracle_binding as oracle  # noqa: E402
-from test_random_scenes import random_scene, random_scene_r3, wide_scene  # noqa: E402
+from test_random_scenes import random_scene, random_scene_r3, scaled_scene, wide_scene  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 FIRST = int(sys.argv[2]) if len(sys.argv) > 2 else 100  # first scene seed
@@ -34,11 +34,14 @@ def make_scene(seed, aspect):
         return scenes.cover(seed, aspect)
     if GEN == "wide":
         return wide_scene(scenes, seed)
+    if GEN == "scaled":
+        return scaled_scene(scenes, seed)
     return random_scene_r3(scenes, seed) if seed % 2 else random_scene(scenes, seed)
 threads = min(256, os.cpu_count() or 8)
 t0 = time.time()
 worst_mae, worst_max, exact, bad_pixels, pixels = 0.0, 0.0, 0, 0, 0
 hist = {}
+over_bar = []
 differing = []  # (seed, W, H, spp, x, y, |diff|) of every pixel that is not bit-identical: candidates for a device-libm branch flip
 for seed in range(FIRST, FIRST + N):
     # every second scene also carries deep transform chains and media inside the boundary of media (round 3)
@@ -66,10 +69,12 @@ for seed in range(FIRST, FIRST + N):
         (ROOT / "gpurun_out" / "random_parity_progress.txt").write_text(f"{seed - FIRST + 1} of {N} scenes, {exact} bit-identical, {time.time() - t0:.0f} s\n")
         print(f"[{seed - FIRST + 1} / {N}] bit-identical {exact}", flush=True)
     if not finite or mae > 1e-4:
-        print("FAIL seed", seed, W, H, spp, mae, nbad, flush=True)
-        sys.exit(1)
+        print("OVER THE BAR: seed", seed, W, H, spp, mae, nbad, flush=True)
+        over_bar.append([seed, W, H, spp, mae, nbad])
+        if GEN == "general":
+            sys.exit(1)
 res = {"scenes": N, "first_seed": FIRST, "max_depth": DEPTH, "generator": GEN, "scale": SCALE, "of_them_with_deep_chains_and_nested_media": N // 2 if GEN == "general" else 0, "bit_identical_scenes": exact, "pixels": pixels, "pixels_differing_by_more_than_1e-12": bad_pixels,
        "worst_mean_abs_error": worst_mae, "worst_abs_diff": worst_max, "differing_pixels_per_scene_histogram": {str(k): v for k, v in sorted(hist.items())},
-       "pixels_not_bit_identical": differing, "seconds": time.time() - t0, "bar": "mean abs error <= 1e-4 per scene"}
+       "scenes_over_the_bar": over_bar, "pixels_not_bit_identical": differing, "seconds": time.time() - t0, "bar": "mean abs error <= 1e-4 per scene"}
 print(res)
 json.dump(res, open(ROOT / "gpurun_out" / ("random_parity.json" if (FIRST, DEPTH, GEN) == (100, 40, "general") else f"random_parity_{GEN}_from_{FIRST}_depth_{DEPTH}" + (f"_x{SCALE}" if SCALE != 1 else "") + ".json"), "w"), indent=1)
