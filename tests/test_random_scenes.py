@@ -278,3 +278,20 @@ def scaled_scene(scenes, seed):
     eye, center, up, fov, aspect, focus, lens = d.camera
     d.camera = (tuple(K * v for v in eye), tuple(K * v for v in center), up, fov, aspect, focus * K, lens * K)
     return d
+
+
+def camera_scene(scenes, seed, aspect):
+    """book-one's spheres under a random camera: eye, centre, up (not unit, not perpendicular), field of view from a sliver to
+    almost pi, focus distance 0.05 ... 200, lens radius 0 ... 2 (src/camera.rs:25-59,91-106 with quirks Q1 and Q2)"""
+    d = scenes.book_one(seed % 50, aspect)
+    rng = np.random.default_rng(seed + 31337)
+    eye = rng.standard_normal(3)
+    eye = eye / np.linalg.norm(eye) * rng.uniform(3.0, 30.0)
+    eye[1] = abs(eye[1]) + 0.3
+    center = rng.uniform(-2.0, 2.0, 3)
+    up = rng.standard_normal(3) * rng.uniform(0.1, 10.0)
+    fov = float(rng.choice([rng.uniform(0.02, 0.2), rng.uniform(0.2, 1.5), rng.uniform(1.5, 3.1)]))
+    focus = float(10.0 ** rng.uniform(-1.3, 2.3))
+    lens = float(rng.choice([0.0, rng.uniform(0.0, 0.2), rng.uniform(0.2, 2.0)]))
+    d.camera = (tuple(eye), tuple(center), tuple(up), fov, float(aspect), focus, lens)
+    return d

@@ -28,7 +28,7 @@ subprocess.run(["make", "-C", str(ROOT / "tests")], check=True, capture_output=T
 rt = load_package()
 scenes = importlib.import_module("ray_tracer_amd.scenes")
 import lane_emul_binding as le  # noqa: E402
-from test_random_scenes import random_scene, random_scene_r3, scaled_scene, wide_scene  # noqa: E402
+from test_random_scenes import camera_scene, random_scene, random_scene_r3, scaled_scene, wide_scene  # noqa: E402
 
 NAMES = ("log", "sin", "atan2", "acos")
 
@@ -52,7 +52,7 @@ if not probe.exists():
 for c in json.load(open(probe)):
     seed, W, H, spp, x, y = (c[k] for k in ("seed", "W", "H", "spp", "x", "y"))
     gen = c.get("generator", "general")
-    d = (scenes.book_one(seed, W / H) if gen == "book_one" else scenes.cover(seed, W / H) if gen == "cover" else wide_scene(scenes, seed) if gen == "wide" else scaled_scene(scenes, seed) if gen == "scaled" else
+    d = (scenes.book_one(seed, W / H) if gen == "book_one" else scenes.cover(seed, W / H) if gen == "cover" else wide_scene(scenes, seed) if gen == "wide" else scaled_scene(scenes, seed) if gen == "scaled" else camera_scene(scenes, seed, W / H) if gen == "camera" else
          random_scene_r3(scenes, seed) if seed % 2 else random_scene(scenes, seed))
     sc, cam = scenes.build_product(d, device=-1)
     depth = int(c.get("max_depth", 40))

@@ -18,7 +18,7 @@ from __graft_entry__ import load_package  # noqa: E402
 rt = load_package()
 scenes = importlib.import_module("ray_tracer_amd.scenes")
 import oracle_binding as oracle  # noqa: E402
-from test_random_scenes import random_scene, random_scene_r3, scaled_scene, wide_scene  # noqa: E402
+from test_random_scenes import camera_scene, random_scene, random_scene_r3, scaled_scene, wide_scene  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 FIRST = int(sys.argv[2]) if len(sys.argv) > 2 else 100  # first scene seed
@@ -36,6 +36,8 @@ def make_scene(seed, aspect):
         return wide_scene(scenes, seed)
     if GEN == "scaled":
         return scaled_scene(scenes, seed)
+    if GEN == "camera":
+        return camera_scene(scenes, seed, aspect)
     return random_scene_r3(scenes, seed) if seed % 2 else random_scene(scenes, seed)
 threads = min(256, os.cpu_count() or 8)
 t0 = time.time()
