@@ -845,16 +845,6 @@ RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack
     tv.cur = L.root;
 }
 
-// take over a segment that another lane began (the ray exchange of rt_kernels.hip): o, d and the result of the hoisted
-// tests (best_t, best_prim) travelled; everything else of the traversal state is a function of those
-RT_HD void trav_resume(const RtLaunch &L, V3 o, V3 d, Trav &tv) {
-    trav_ray_constants(L, o, d, tv);
-    tv.r2a = world_roots_rcp(L, o, dot(d, d));
-    tv.best32 = up32(tv.best_t);
-    tv.sp = 0;
-    tv.cur = L.root;
-}
-
 // one inner-node step (tv.cur is an inner node reference).  `nodes` is the node array (LDS copy or global).
 // Slab test of BOTH children: per axis the ray's entry plane and exit plane are read as (child0, child1) pairs through
 // the per-ray offsets tv.ox/oy/oz -- 12 fused multiply-adds and two max3 / min3 per node instead of testing all four
