@@ -297,6 +297,10 @@ int rt_scene_prim_bounds(const rt_scene *, int prim, double out[6]);
 /* ---- device self-test used by the GPU parity tests: evaluates sqrt, div on the
  *      device for n inputs so the host can check they are correctly rounded ---- */
 int rt_probe_device_math(int device, const double *a, const double *b, int n, double *out_sqrt_a, double *out_a_div_b);
+/* ... and the kernels' transcendentals -- the host libm's functions restated for the device (csrc/rt_libm.h), standing
+ * for `f64::ln` (src/volume.rs:59-60,81-82), `sin` (src/material.rs:238), `acos` and `atan2` (src/geometry.rs:35-39):
+ * which = 0 log(a), 1 sin(a), 2 acos(a), 3 atan2(a, b); the GPU tests compare the results with glibc's bit for bit */
+int rt_probe_device_libm(int device, int which, const double *a, const double *b, int n, double *out);
 
 #define RT_FEAT_SPHERE_T 1u   /* translation-only sphere sprites */
 #define RT_FEAT_GENERAL 2u    /* sprites with a general matrix / rectangles / cubes */

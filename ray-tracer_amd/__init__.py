@@ -141,6 +141,7 @@ ABI = {
     "rt_scene_hash": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     "rt_scene_prim_bounds": (C.c_int, [_VP, C.c_int, _DP]),
     "rt_probe_device_math": (C.c_int, [C.c_int, _DP, _DP, C.c_int, _DP, _DP]),
+    "rt_probe_device_libm": (C.c_int, [C.c_int, C.c_int, _DP, _DP, C.c_int, _DP]),
 }
 
 _lib = None
@@ -450,7 +451,7 @@ def tonemap_png8(img: np.ndarray) -> np.ndarray:
     return out
 
 
-HASHED_SOURCES = ("csrc/rt_kernels.hip", "csrc/rt_lane.h", "csrc/rt_types.h", "csrc/rt_lds.h", "csrc/rt_host.cpp", "csrc/rt_host.h", "csrc/rt_api.cpp",
+HASHED_SOURCES = ("csrc/rt_kernels.hip", "csrc/rt_lane.h", "csrc/rt_libm.h", "csrc/rt_libm_tables.h", "csrc/rt_types.h", "csrc/rt_lds.h", "csrc/rt_host.cpp", "csrc/rt_host.h", "csrc/rt_api.cpp",
                   "csrc/rt_scene_priv.h", "../include/rt_mi355x.h", "../include/rt_rng.h", "csrc/Makefile")
 
 
@@ -480,6 +481,18 @@ def source_hash() -> str:
 
 def device_count() -> int:
     return int(lib().rt_device_count())
+
+
+LIBM_FUNCTIONS = ("log", "sin", "acos", "atan2")
+
+
+def probe_device_libm(which: str, a: np.ndarray, b: np.ndarray = None, device=0) -> np.ndarray:
+    """the kernels' log / sin / acos / atan2 (a, b) on the device (csrc/rt_libm.h)"""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(a if b is None else b, dtype=np.float64)
+    out = np.zeros_like(a)
+    _check(lib().rt_probe_device_libm(device, LIBM_FUNCTIONS.index(which), _dp(a), _dp(b), a.size, _dp(out)))
+    return out
 
 
 def probe_device_math(a: np.ndarray, b: np.ndarray, device=0):

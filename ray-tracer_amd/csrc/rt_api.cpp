@@ -33,6 +33,7 @@ extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int 
 extern "C" int rt_launch_unpack(const double *gathered, int tiles_per_shard, int shard_count, int width, int height,
                                 double *image, void *stream);
 extern "C" int rt_launch_probe_math(const double *a, const double *b, int n, double *out_sqrt, double *out_div, void *stream);
+extern "C" int rt_launch_probe_libm(int which, const double *a, const double *b, int n, double *out, void *stream);
 
 namespace {
 
@@ -1006,6 +1007,24 @@ int rt_probe_device_math(int device, const double *a, const double *b, int n, do
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out_sqrt, d[2], bytes, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out_div, d[3], bytes, hipMemcpyDeviceToHost));
+    for (auto &p : d) (void)hipFree(p);
+    return RT_OK;
+}
+
+int rt_probe_device_libm(int device, int which, const double *a, const double *b, int n, double *out) {
+    if (!a || !b || !out || n <= 0 || which < 0 || which > 3) return fail(RT_ERR_INVALID, "bad argument");
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || device < 0 || device >= cnt) return fail(RT_ERR_DEVICE, "no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    double *d[3] = {nullptr, nullptr, nullptr};
+    const size_t bytes = (size_t)n * sizeof(double);
+    for (auto &p : d) HIP_TRY(hipMalloc((void **)&p, bytes));
+    HIP_TRY(hipMemcpy(d[0], a, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d[1], b, bytes, hipMemcpyHostToDevice));
+    int rc = rt_launch_probe_libm(which, d[0], d[1], n, d[2], nullptr);
+    if (rc != 0) return hip_fail((hipError_t)rc, "probe kernel launch");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, d[2], bytes, hipMemcpyDeviceToHost));
     for (auto &p : d) (void)hipFree(p);
     return RT_OK;
 }

@@ -841,6 +841,20 @@ __global__ void probe_math_kernel(const double *a, const double *b, int n, doubl
     out_div[i] = a[i] / b[i];
 }
 
+// the product's own transcendentals (rt_libm.h, what log_cold / sphere_uv_cold / checker_sine_cold call) on n arguments
+__global__ void probe_libm_kernel(int which, const double *a, const double *b, int n, double *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double r;
+    switch (which) {
+    case 0: r = rtm::log(a[i]); break;
+    case 1: r = rtm::sin(a[i]); break;
+    case 2: r = rtm::acos(a[i]); break;
+    default: r = rtm::atan2(a[i], b[i]); break;
+    }
+    out[i] = r;
+}
+
 #endif // parts 0 / 1
 
 // ---- dispatch over the template instantiations ----
@@ -990,6 +1004,12 @@ extern "C" int rt_launch_unpack(const double *gathered, int tiles_per_shard, int
     const int tiles_x = (width + RT_TILE_EDGE - 1) / RT_TILE_EDGE;
     hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gathered,
                        tiles_per_shard, shard_count, width, height, tiles_x, image);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int rt_launch_probe_libm(int which, const double *a, const double *b, int n, double *out, void *stream) {
+    hipLaunchKernelGGL(probe_libm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, which, a, b, n, out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

@@ -13,6 +13,7 @@
 #define RT_LANE_H
 
 #include "../../include/rt_rng.h"
+#include "rt_libm.h"
 #include "rt_types.h"
 
 #include <math.h>
@@ -323,27 +324,36 @@ RT_HD bool sphere_t(V3 oc, V3 d, double a, double radius, double *t_out, double 
     return true;
 }
 // ---- out-of-line transcendental helpers ----
-// atan2 / acos / sin / log expand to binary64 polynomials with a dozen 64-bit constants each.  Inlined into the
-// persistent kernel loop, the compiler hoists every one of those constants out of the loop and keeps them in registers for
-// the kernel's whole life (+70 VGPRs: 222 instead of 153, the difference between 2 and 3 waves per SIMD).  As real
-// functions they cost a call on paths that are rare (textured hits) or already expensive (a medium test).
+// atan2 / acos / sin / log are the HOST libm's functions restated (rt_libm.h: glibc 2.35's algorithms, its roundings and
+// its tables), because that is what the reference calls (`f64::atan2 / acos / sin / ln`) and the device's own library is an
+// ulp away from it on 3-27 % of arguments.  Each expands to binary64 polynomials with a dozen 64-bit constants.  Inlined
+// into the persistent kernel loop, the compiler hoists every one of those constants out of the loop and keeps them in
+// registers for the kernel's whole life (+70 VGPRs, the difference between 2 and 3 waves per SIMD).  As real functions
+// they cost a call on paths that are rare (textured hits) or already expensive (a medium test).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RT_COLD __device__ __attribute__((noinline))
 #else
 #define RT_COLD static inline
+#endif
+// (tests/lane_emul.cpp defines RTL_LOG ... before this header to record the arguments a path passes to them)
+#if !defined(RTL_LOG)
+#define RTL_LOG(x) rtm::log(x)
+#define RTL_SIN(x) rtm::sin(x)
+#define RTL_ATAN2(y, x) rtm::atan2(y, x)
+#define RTL_ACOS(x) rtm::acos(x)
 #endif
 struct UV {
     double u, v;
 };
 RT_COLD UV sphere_uv_cold(double qx, double qy, double qz) { // unitSphereUv, src/geometry.rs:35-39
     UV r;
-    r.u = 0.5 + atan2(qx, qz) / (2.0 * RTL_PI);
-    r.v = 1.0 - acos(qy) / RTL_PI;
+    r.u = 0.5 + RTL_ATAN2(qx, qz) / (2.0 * RTL_PI);
+    r.v = 1.0 - RTL_ACOS(qy) / RTL_PI;
     return r;
 }
-RT_COLD double log_cold(double x) { return log(x); }
+RT_COLD double log_cold(double x) { return RTL_LOG(x); }
 RT_COLD double checker_sine_cold(double u, double v) { // src/material.rs:238
-    return sin(2.0 * RTL_PI * 10.0 * u) * sin(2.0 * RTL_PI * 10.0 * v);
+    return RTL_SIN(2.0 * RTL_PI * 10.0 * u) * RTL_SIN(2.0 * RTL_PI * 10.0 * v);
 }
 RT_HD void sphere_uv(V3 q, double *u, double *v) {
     const UV r = sphere_uv_cold(q.x, q.y, q.z);

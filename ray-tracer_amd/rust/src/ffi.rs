@@ -240,4 +240,12 @@ extern "C" {
         out_sqrt_a: *mut c_double,
         out_a_div_b: *mut c_double,
     ) -> c_int;
+    pub fn rt_probe_device_libm(
+        device: c_int,
+        which: c_int,
+        a: *const c_double,
+        b: *const c_double,
+        n: c_int,
+        out: *mut c_double,
+    ) -> c_int;
 }

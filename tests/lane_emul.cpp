@@ -18,6 +18,7 @@
 #include <cstring>
 #include <math.h>
 #include <vector>
+#include "../ray-tracer_amd/csrc/rt_libm.h" // the kernels' log / sin / atan2 / acos (the host libm's, restated)
 namespace lane_trace {
 struct Call {
     int sample, fn; // fn: 0 log, 1 sin, 2 atan2, 3 acos
@@ -31,7 +32,7 @@ static inline double rec(int fn, double a, double b, double r) {
 }
 static int perturb_log = 0; // lane_emul_set_log_perturbation: move log's result by one ulp for about 1 argument in N (a stand-in for a libm that is not correctly rounded)
 static inline double t_log(double x) {
-    double r = ::log(x);
+    double r = rtm::log(x);
     if (perturb_log > 0) {
         uint64_t b;
         memcpy(&b, &x, sizeof b);
@@ -40,19 +41,15 @@ static inline double t_log(double x) {
     }
     return rec(0, x, 0.0, r);
 }
-static inline double t_sin(double x) { return rec(1, x, 0.0, ::sin(x)); }
-static inline double t_atan2(double y, double x) { return rec(2, y, x, ::atan2(y, x)); }
-static inline double t_acos(double x) { return rec(3, x, 0.0, ::acos(x)); }
+static inline double t_sin(double x) { return rec(1, x, 0.0, rtm::sin(x)); }
+static inline double t_atan2(double y, double x) { return rec(2, y, x, rtm::atan2(y, x)); }
+static inline double t_acos(double x) { return rec(3, x, 0.0, rtm::acos(x)); }
 } // namespace lane_trace
-#define log(x) lane_trace::t_log(x)
-#define sin(x) lane_trace::t_sin(x)
-#define atan2(y, x) lane_trace::t_atan2(y, x)
-#define acos(x) lane_trace::t_acos(x)
+#define RTL_LOG(x) lane_trace::t_log(x)
+#define RTL_SIN(x) lane_trace::t_sin(x)
+#define RTL_ATAN2(y, x) lane_trace::t_atan2(y, x)
+#define RTL_ACOS(x) lane_trace::t_acos(x)
 #include "../ray-tracer_amd/csrc/rt_lane.h"
-#undef log
-#undef sin
-#undef atan2
-#undef acos
 #include "../ray-tracer_amd/csrc/rt_lds.h"
 #include "../ray-tracer_amd/csrc/rt_scene_priv.h"
 #include "../include/rt_mi355x.h"

@@ -1,0 +1,120 @@
+"""csrc/rt_libm.h (the kernels' log / sin / acos / atan2) against the HOST's libm, bit for bit, on the CPU.
+
+The reference calls the platform libm (`f64::ln`, `sin`, `acos`, `atan2`; src/volume.rs:59-60,81-82, src/geometry.rs:35-39,
+src/material.rs:238) and the oracle calls the same functions of glibc.  rt_libm.h restates glibc 2.35's algorithms
+(x86-64, the FMA builds its ifunc resolvers select) so that the kernels return those bits; here its HOST compilation is
+compared with the installed library itself -- which pins the transcription and the extracted tables together.  The device
+compilation of the same header is compared with the same library in tests/test_gpu_parity.py."""
+import platform
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def lm(lane_emul):  # lane_emul's fixture runs tests/Makefile, which builds liblibm_emul.so as well
+    if "glibc" not in platform.libc_ver()[0] or not platform.libc_ver()[1].startswith("2.35"):
+        pytest.skip("the restatement is of glibc 2.35 (the image's libm); this host has " + "-".join(platform.libc_ver()))
+    flags = open("/proc/cpuinfo").read()
+    if " fma " not in flags or " avx2 " not in flags:
+        pytest.skip("glibc selects its FMA builds only on CPUs with FMA + AVX2; rt_libm.h restates those")
+    import libm_emul_binding
+    return libm_emul_binding
+
+
+def random_bits(rng, n):
+    """uniform over bit patterns: every exponent, both signs, denormals, infinities, NaNs"""
+    return rng.integers(0, 2 ** 64, n, dtype=np.uint64).view(np.float64)
+
+
+def signs(rng, n):
+    return rng.choice([-1.0, 1.0], n)
+
+
+N = 1_000_000
+SPECIAL = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 1e-310, 2.2250738585072014e-308, 2.0, -2.0,
+                    1e308, -1e308, 0.5, -0.5, 0.0625, 16.0, 0.126, 0.855469, 2.426265, 105414350.0, 105414357.85,
+                    0.125, 0.25, 0.75, 0.921875, 0.953125, 0.96875, 1.0 - 2.0 ** -53, 1.0 + 2.0 ** -52, 0.9375, 1.0647,
+                    np.pi, np.pi / 2, np.pi / 4, 3 * np.pi / 4, 2.0 ** -26, 2.0 ** -27, 2.0 ** -55, 2.0 ** -56, 2.0 ** 1023])
+
+
+def check(lm, which, a, b=None):
+    bad, first = lm.count_diffs(which, a, b)
+    if bad:
+        x = (a[first],) if b is None else (a[first], b[first])
+        mine, host = lm.evaluate(which, *x)
+        pytest.fail(f"{which}{tuple(float(v).hex() for v in x)}: rt_libm.h {mine[0].hex()} != libm {host[0].hex()} "
+                    f"({bad} of {a.size} arguments differ)")
+
+
+def test_the_harness_can_see_a_difference(lm):
+    """one ulp is enough to fail: the comparison is on bits"""
+    mine, host = lm.evaluate("log", np.array([0.3]))
+    assert lm.same_bits(mine, host).all() and not lm.same_bits(np.nextafter(mine, 0.0), host).any()
+    assert lm.same_bits(np.array([np.nan]), np.array([-np.nan])).all()
+
+
+def test_log_equals_the_host_libm(lm):
+    rng = np.random.default_rng(101)
+    check(lm, "log", rng.random(4 * N))                                       # what a free-flight draw passes: [0, 1), 53 bits
+    check(lm, "log", (rng.integers(0, 2 ** 53, N, dtype=np.uint64)).astype(np.float64) * 2.0 ** -53)
+    check(lm, "log", 1.0 + rng.uniform(-0.07, 0.07, N))                        # the series around 1
+    check(lm, "log", np.exp(rng.uniform(-745.0, 709.0, N)))                    # every exponent
+    check(lm, "log", rng.integers(0, 2 ** 52, N, dtype=np.uint64).view(np.float64))  # denormals
+    check(lm, "log", random_bits(rng, N))
+    check(lm, "log", np.concatenate([SPECIAL, -SPECIAL]))
+
+
+def test_sin_equals_the_host_libm(lm):
+    rng = np.random.default_rng(102)
+    check(lm, "sin", 20.0 * np.pi * rng.random(4 * N))                         # src/material.rs:238 on uv in [0, 1)
+    check(lm, "sin", rng.uniform(-0.9, 0.9, N))
+    check(lm, "sin", rng.uniform(-2.5, 2.5, N))
+    check(lm, "sin", rng.uniform(-130.0, 130.0, N))
+    check(lm, "sin", np.exp(rng.uniform(-40.0, 0.0, N)) * signs(rng, N))
+    check(lm, "sin", rng.uniform(-1.1e8, 1.1e8, N))                            # both sides of the switch to __branred
+    check(lm, "sin", np.exp(rng.uniform(18.0, 709.7, N)) * signs(rng, N))      # __branred
+    check(lm, "sin", random_bits(rng, N))
+    k = np.arange(-4000, 4000)                                                  # next to multiples of pi / 2: deep cancellation
+    near = np.concatenate([np.nextafter(k * (np.pi / 2), np.inf), k * (np.pi / 2), np.nextafter(k * (np.pi / 2), -np.inf)])
+    check(lm, "sin", near)
+    check(lm, "sin", np.concatenate([SPECIAL, -SPECIAL]))
+
+
+def test_acos_equals_the_host_libm(lm):
+    rng = np.random.default_rng(103)
+    check(lm, "acos", rng.uniform(-1.0, 1.0, 4 * N))
+    v = rng.normal(size=(N, 3))
+    check(lm, "acos", v[:, 1] / np.sqrt((v * v).sum(axis=1)))                  # the y of a unit vector: src/geometry.rs:37
+    check(lm, "acos", (1.0 - np.exp(rng.uniform(-37.0, -3.0, N))) * signs(rng, N))  # 0.96875 <= |x| < 1
+    check(lm, "acos", np.exp(rng.uniform(-45.0, -1.0, N)) * signs(rng, N))
+    for lo, hi in ((0.125, 0.5), (0.5, 0.75), (0.75, 0.921875), (0.921875, 0.953125), (0.953125, 0.96875), (0.96875, 1.0)):
+        check(lm, "acos", rng.uniform(lo, hi, N // 4) * signs(rng, N // 4))
+    edges = np.array([0.125, 0.25, 0.5, 0.75, 0.921875, 0.953125, 0.96875, 1.0])
+    near = np.concatenate([np.nextafter(edges, 0.0), edges, np.nextafter(edges, 2.0)])
+    check(lm, "acos", np.concatenate([near, -near]))
+    check(lm, "acos", random_bits(rng, N))
+    check(lm, "acos", np.concatenate([SPECIAL, -SPECIAL]))
+
+
+def test_atan2_equals_the_host_libm(lm):
+    rng = np.random.default_rng(104)
+    v = rng.normal(size=(4 * N, 3))
+    v /= np.sqrt((v * v).sum(axis=1))[:, None]
+    check(lm, "atan2", v[:, 0], v[:, 2])                                       # (x, z) of a unit vector: src/geometry.rs:36
+    th = rng.uniform(-np.pi, np.pi, N)
+    check(lm, "atan2", np.sin(th), np.cos(th))
+    check(lm, "atan2", rng.normal(size=N), rng.normal(size=N))
+    wide = lambda: np.exp(rng.uniform(-700.0, 700.0, N)) * signs(rng, N)  # noqa: E731
+    check(lm, "atan2", wide(), wide())
+    check(lm, "atan2", np.exp(rng.uniform(-45.0, 45.0, N)) * signs(rng, N), rng.uniform(0.5, 2.0, N) * signs(rng, N))
+    u = rng.uniform(0.0, 1.0, N)                                               # every table interval, all four quadrants
+    check(lm, "atan2", u * signs(rng, N), signs(rng, N))
+    check(lm, "atan2", signs(rng, N), u * signs(rng, N))
+    k = np.arange(16, 257) / 256.0                                             # the interval edges themselves
+    for y, x in ((k, np.ones_like(k)), (np.ones_like(k), k), (k, -np.ones_like(k)), (-np.ones_like(k), -k)):
+        check(lm, "atan2", np.concatenate([np.nextafter(y, 0.0), y, np.nextafter(y, 2.0)]), np.concatenate([x, x, x]))
+    check(lm, "atan2", random_bits(rng, N), random_bits(rng, N))
+    sp = np.concatenate([SPECIAL, -SPECIAL])
+    yy, xx = np.meshgrid(sp, sp)
+    check(lm, "atan2", yy.ravel().copy(), xx.ravel().copy())
