@@ -251,6 +251,9 @@ void make_xform(const double M[16], const double Minv[16], RtXform *x) {
             x->m[r * 4 + c] = M[c * 4 + r];
             x->inv[r * 4 + c] = Minv[c * 4 + r];
         }
+    x->box[0] = std::numeric_limits<double>::quiet_NaN(); // no reference box (set_ref_box)
+    for (int i = 1; i < 6; ++i) x->box[i] = 0.0;
+    x->pad_[0] = x->pad_[1] = 0.0;
 }
 
 // x' = m0*x + m4*y + m8*z + m12*w, evaluated left to right (src/vec4.rs:78-91)
@@ -346,8 +349,13 @@ namespace {
 struct Link {
     double M[16], Minv[16];
     bool translation; // M and M^-1 are pure translations by t and -t: only the offsets enter the arithmetic
+    // the reference's Bound of the object that carries this transform, in the frame above it, when that object is a child of a
+    // BoundingVolumeHierarchyNode (RtXform::box)
+    bool has_box = false;
+    Aabb box{};
 };
 bool make_link(const double M[16], Link *l) {
+    l->has_box = false;
     std::memcpy(l->M, M, sizeof l->M);
     if (!mat4_inversed(M, l->Minv)) return false; // det == 0: unhittable (src/sprite.rs:131-134, src/geometry.rs:241-244)
     l->translation = is_pure_translation(M) && is_pure_translation(l->Minv) && l->Minv[12] == -M[12] && l->Minv[13] == -M[13] &&
@@ -403,6 +411,17 @@ Aabb chain_bound(const Aabb &local, const std::vector<Link> &outer, const std::v
 }
 Aabb shape_local_bound(const Shape &s) { return s.kind == RT_PRIM_SPHERE_C ? sphere_bound(s.a) : rect_bound(s.a, s.b); }
 
+// Bound for Sprite / TransformedGeometry (src/optimize.rs:128-241): the AABB of the inner bound's 8 corners under M
+Aabb corners_bound(const Aabb &inner, const double M[16]) {
+    Link l;
+    std::memcpy(l.M, M, sizeof l.M);
+    return chain_bound(inner, {l}, {});
+}
+void set_ref_box(Link *l, const Aabb &inner) {
+    l->has_box = true;
+    l->box = corners_bound(inner, l->M);
+}
+
 struct Flattener {
     const SceneIR &ir;
     FlatScene &fs;
@@ -417,6 +436,58 @@ struct Flattener {
             error = msg;
         }
         return false;
+    }
+
+    // `Bound::bound` of geometry `gi` in its own frame, as the reference computes it (src/optimize.rs:98-241,502-516): sphere and
+    // rectangle boxes, the 8-corner boxes of TransformedGeometry / Sprite, the union a BoundingVolumeHierarchyNode keeps as its
+    // volume (min / max are exact, so the shape of the random tree does not enter), the boundary's for a ConstantMedium.
+    // false: None (an empty node, only unhittable children)
+    bool ref_bound(int gi, Aabb *out, int depth = 0) {
+        if (gi < 0 || depth > 16) return false;
+        const GeometryIR &g = ir.geometries[(size_t)gi];
+        switch (g.kind) {
+        case GEO_SPHERE:
+            *out = sphere_bound(g.p[0]);
+            return true;
+        case GEO_RECTANGLE:
+            *out = rect_bound(g.p[0], g.p[1]);
+            return true;
+        case GEO_CUBE: {
+            CubeFace f[6];
+            cube_faces(g.p[0], g.p[1], g.p[2], f);
+            for (int i = 0; i < 6; ++i) {
+                const Aabb b = corners_bound(rect_bound(f[i].w, f[i].h), f[i].M);
+                *out = i ? merged(*out, b) : b;
+            }
+            return true;
+        }
+        case GEO_TRANSFORMED: {
+            Aabb in;
+            if (!ref_bound(g.boundary, &in, depth + 1)) return false;
+            *out = corners_bound(in, g.M);
+            return true;
+        }
+        case GEO_BVH: {
+            bool any = false;
+            for (int si : g.children) {
+                const SpriteIR &sp = ir.sprites[(size_t)si];
+                Aabb in;
+                if (sp.geometry < 0 || !ref_bound(sp.geometry, &in, depth + 1)) continue;
+                const Aabb b = corners_bound(in, sp.M);
+                *out = any ? merged(*out, b) : b;
+                any = true;
+            }
+            return any;
+        }
+        case GEO_MEDIUM:
+            return ref_bound(g.boundary, out, depth + 1);
+        }
+        return false;
+    }
+    // a sprite (of the world's list or of a node geometry) is a child of a BoundingVolumeHierarchyNode: its box is tested
+    void sprite_box(Link *l, int geometry) {
+        Aabb in;
+        if (ref_bound(geometry, &in)) set_ref_box(l, in);
     }
 
     // every sphere / rectangle below geometry `gi`, each with the transforms between it and `chain`'s end appended
@@ -437,6 +508,7 @@ struct Flattener {
             for (const CubeFace &face : f) {
                 Link l;
                 if (!make_link(face.M, &l)) continue;
+                set_ref_box(&l, rect_bound(face.w, face.h)); // a child of the Cube's BoundingVolumeHierarchyNode
                 std::vector<Link> c = chain;
                 c.push_back(l);
                 out->push_back(Shape{RT_PRIM_RECT_C, face.w, face.h, c, {}, 0u});
@@ -455,6 +527,7 @@ struct Flattener {
                 if (sp.geometry < 0) continue;
                 Link l;
                 if (!make_link(sp.M, &l)) continue;
+                sprite_box(&l, sp.geometry);
                 std::vector<Link> c = chain;
                 c.push_back(l);
                 if (!collect_shapes(sp.geometry, c, out, depth + 1, path_hash * RT_RNG_PATH_MUL + (uint64_t)k + 1ull, media)) return false;
@@ -593,6 +666,7 @@ struct Flattener {
                 if (sp.geometry < 0) continue; // geometry None: never hit (src/sprite.rs:95,136)
                 Link l;
                 if (!make_link(sp.M, &l)) continue;
+                sprite_box(&l, sp.geometry);
                 std::vector<Link> c = chain;
                 c.push_back(l);
                 // the child's position in its node, not its creation index: independent of the order a front end records sprites in
@@ -651,6 +725,11 @@ uint32_t push_chain(FlatScene &fs, const std::vector<Link> &chain) {
     for (const Link &l : chain) {
         RtXform x;
         make_xform(l.M, l.Minv, &x);
+        if (l.has_box)
+            for (int i = 0; i < 3; ++i) {
+                x.box[i] = l.box.lo[i];
+                x.box[3 + i] = l.box.hi[i];
+            }
         fs.xforms.push_back(x);
     }
     return first;
@@ -719,6 +798,7 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
         if (s.geometry < 0) continue; // geometry None: never hit (src/sprite.rs:95,136)
         Link l;
         if (!make_link(s.M, &l)) continue; // det == 0: unhittable (src/sprite.rs:131-134)
+        fl.sprite_box(&l, s.geometry);       // a child of the world's BoundingVolumeHierarchyNode
         const uint32_t material = s.material < 0 ? RT_NO_MATERIAL : (uint32_t)s.material;
         if (!fl.emit(s.geometry, {l}, material, my_rank + 1ull, 1, slot, 0)) {
             if (err) *err = fl.error;

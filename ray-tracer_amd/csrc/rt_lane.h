@@ -55,6 +55,17 @@ static inline float rtl_emul_rcp32(float x) { // v_rcp_f32's 1 ulp: the correctl
 #define RTL_RCP64(x) rtl::rtl_emul_rcp64(x)
 #define RTL_OUT_OF_LINE static inline
 #endif
+// high word of a binary64 (sign, exponent, 20 mantissa bits)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_HI32(x) ((uint32_t)__double2hiint(x))
+#else
+static inline uint32_t rt_hi32(double x) {
+    uint64_t b;
+    memcpy(&b, &x, sizeof b);
+    return (uint32_t)(b >> 32);
+}
+#define RT_HI32(x) rtl::rt_hi32(x)
+#endif
 RT_HD uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 RT_HD uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 #define RTL_PI 3.14159265358979323846264338327950288
@@ -533,6 +544,63 @@ RT_HD void chain_up_point(const RtLaunch &L, uint32_t first, uint32_t len, uint3
     }
 }
 
+// ---- the reference's own boxes, for the one class of ray on which they are NOT result-neutral ----
+// Everywhere else the binary32 culling boxes stand in for AxisAlignedBoundingBox::hit because a box never rejects what the
+// primitive inside it accepts (F7): the primitive's extent lies inside its box, and a ray that crosses a box plane does so with a
+// slab interval far wider than any rounding.  That premise fails for a ray that runs IN a box's boundary plane -- a direction
+// component that is exactly zero (1 / 0 = inf; (plane - o) * inf is NaN when o sits on the plane, and the axis drops out of the
+// reference's selects, but +-inf when o is one rounding error beyond it: both ends of the slab the same infinity, the box and
+// everything in it dropped, src/optimize.rs:61-82,469-498) or so small (1e-17 of the others) that the ray moves less than an
+// ulp of its own coordinates across the whole scene: whether such a ray is "in" a box whose plane it runs along is decided by
+// the last bit of o, while the primitive's own test reaches the same plane through a different chain of roundings and compares
+// inclusively (src/geometry.rs:153-180).  Seen on rays that leave a cube's face ALONG the face, and then run along its edges,
+// after the degenerate refraction of scenes scaled up 1e8-fold (profiles/r04_boundary_plane_probe.json).  So a hit found on a
+// segment whose direction is that close to an axis plane is put through the binary64 boxes the reference keeps for the objects
+// above the primitive -- each object's OWN box (RtXform::box), i.e. the answer of every tree in which that object sits in a node
+// of its own; where the reference's random trees disagree with one another (a box shared with a sibling can be larger) this is
+// one of their answers.  For any other ray the boxes admit what the primitive accepts, so the gate only decides who pays.
+// near_axis: some component is zero or below 2^-20 of the largest (compared through the exponent fields)
+RT_HD bool near_axis(V3 d) {
+    const uint32_t ex = RT_HI32(d.x) & 0x7FFFFFFFu, ey = RT_HI32(d.y) & 0x7FFFFFFFu, ez = RT_HI32(d.z) & 0x7FFFFFFFu;
+    return umin(umin(ex, ey), ez) + (20u << 20) <= umax(umax(ex, ey), ez);
+}
+// AxisAlignedBoundingBox::hit (src/optimize.rs:61-82): t in [0, inf), the reference's selects and their NaN behaviour
+RT_HD bool ref_slab(double lo, double hi, double o, double d, double *tmin, double *tmax) { // one axis of the loop
+    const double inv = 1.0 / d;
+    double t0 = (lo - o) * inv;
+    double t1 = (hi - o) * inv;
+    if (inv < 0.0) {
+        const double t = t0;
+        t0 = t1;
+        t1 = t;
+    }
+    *tmin = t0 > *tmin ? t0 : *tmin;
+    *tmax = t1 < *tmax ? t1 : *tmax;
+    return !(*tmax <= *tmin);
+}
+RT_HD bool ref_box_hit(const double *b, V3 o, V3 d) { // b: lo[3], hi[3]
+    double tmin = 0.0, tmax = RTL_INF;
+    return ref_slab(b[0], b[3], o.x, d.x, &tmin, &tmax) && ref_slab(b[1], b[4], o.y, d.y, &tmin, &tmax) &&
+           ref_slab(b[2], b[5], o.z, d.z, &tmin, &tmax);
+}
+// the boxes of a chain's levels, each against the ray in the frame above the level (chain_down's arithmetic level by level)
+template <bool DEEP>
+RT_COLD bool chain_boxes_admit(const RtLaunch &L, uint32_t first, uint32_t len, uint32_t tmask, V3 o, V3 d) {
+    for (uint32_t i = 0; i < len; ++i) {
+        if (!DEEP && i >= (uint32_t)RT_MAX_CHAIN) break;
+        const RtXform &X = rec_at(L.xforms, first + i);
+        if (X.box[0] == X.box[0] && !ref_box_hit(X.box, o, d)) return false;
+        if (i < (uint32_t)RT_MAX_CHAIN && ((tmask >> i) & 1u)) {
+            o = mk(o.x + X.inv[3], o.y + X.inv[7], o.z + X.inv[11]);
+        } else {
+            const V3 lo = xf_point(X.inv, o);
+            d = xf_vector(X.inv, d);
+            o = lo;
+        }
+    }
+    return true;
+}
+
 // sphere / rectangle in its own frame.  RECORD = false: only r->t is meaningful
 template <bool RECORD>
 RT_HD bool shape_hit(uint32_t kind, const RtPrimGeo &G, V3 lo, V3 ld, bool uv, Rec *r) {
@@ -570,6 +638,7 @@ RT_HD bool medium_general_hit(const RtLaunch &L, const RtPrimGeo &G, V3 o, V3 d,
     const uint32_t first = (uint32_t)G.g[1], count = (uint32_t)G.g[2];
     Rec r1, r2;
     V3 ro = o;
+    const bool zd = near_axis(d);
     for (int pass = 0; pass < 2; ++pass) { // boundary.hit(ray), then boundary.hit(restarted ray)
         Rec best;
         bool have = false;
@@ -592,6 +661,8 @@ RT_HD bool medium_general_hit(const RtLaunch &L, const RtPrimGeo &G, V3 o, V3 d,
             } else {
                 hit = shape_hit<true>(kw & 0xFFu, rec_at(L.prim_geo, ci), co, cd, uv, &cr);
             }
+            // (the boundary's own nodes -- a Cube, a node of sprites -- keep boxes too)
+            if (hit && zd && !chain_boxes_admit<true>(L, cf, cl, cm, ro, d)) hit = false;
             if (hit && (!have || cr.t < best.t)) {
                 chain_up<true>(L, cf, cl, cm, &cr);
                 best = cr;
@@ -680,6 +751,25 @@ RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx
         return true;
     }
     return false;
+}
+
+// A hit of primitive `pi` on a segment whose direction is (all but) parallel to an axis plane: would the reference's boxes above the
+// primitive have let the ray through (see ref_box_hit)?  Out of line: hardly ever called.
+template <bool GENERAL, int MEDIUM>
+RT_COLD bool own_boxes_admit(const RtLaunch &L, uint32_t pi, V3 o, V3 d) {
+    const RtPrimGeo &G = rec_at(L.prim_geo, pi);
+    uint32_t kw = (uint32_t)RT_PRIM_SPHERE_T;
+    if (GENERAL || MEDIUM) kw = rec_at(L.prim_meta, pi).kind;
+    const uint32_t kind = kw & 0xFFu;
+    if (kind == RT_PRIM_SPHERE_T || kind == RT_PRIM_MEDIUM_T) {
+        // a sprite of the world's list under a pure translation: the 8 corners (+-r, +-r, +-r) through M are +-r + c
+        const double r = fabs(G.g[3]);
+        double tmin = 0.0, tmax = RTL_INF;
+        return ref_slab(-r + G.g[0], r + G.g[0], o.x, d.x, &tmin, &tmax) && ref_slab(-r + G.g[1], r + G.g[1], o.y, d.y, &tmin, &tmax) &&
+               ref_slab(-r + G.g[2], r + G.g[2], o.z, d.z, &tmin, &tmax);
+    }
+    return chain_boxes_admit<(MEDIUM >= 2)>(L, rec_at(L.prim_meta, pi).xform, (kw >> RT_META_CHAIN_SHIFT) & 0xFu,
+                                            (kw >> RT_META_TMASK_SHIFT) & 0xFu, o, d);
 }
 
 // The hit record of primitive `pi` at the parameter t the traversal found (shading).  The same arithmetic as the full test
@@ -841,9 +931,11 @@ RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack
     const double a = dot(d, d);
     tv.r2a = world_roots_rcp(L, o, a);
     sc.r2a = tv.r2a;
+    const bool zd = near_axis(d);
     for (int32_t pi = 0; pi < L.n_hoisted; ++pi) {
         Rec r;
         if (prim_hit<GENERAL, MEDIUM, false>(L, (uint32_t)pi, o, d, a, sc, &r, false)) {
+            if (zd && !own_boxes_admit<GENERAL, MEDIUM>(L, (uint32_t)pi, o, d)) continue; // (hardly ever: see ref_box_hit)
             if (r.t < tv.best_t) { // ascending prim id: ties keep the lower id
                 tv.best_t = r.t;
                 tv.best_prim = (uint32_t)pi;
@@ -944,7 +1036,8 @@ RT_HD void trav_leaf_step(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, S
     const uint32_t pi = tv.cur & Stack::Ref::kMask;
     const double a = dot(d, d);
     Rec r;
-    if (prim_hit<GENERAL, MEDIUM, false>(L, pi, o, d, a, sc, &r, false)) {
+    if (prim_hit<GENERAL, MEDIUM, false>(L, pi, o, d, a, sc, &r, false) &&
+        !(near_axis(d) && !own_boxes_admit<GENERAL, MEDIUM>(L, pi, o, d))) { // (the boxes: hardly ever, see ref_box_hit)
         // nearest t; exact ties go to the lower prim id, whatever the visiting order
         if (r.t < tv.best_t || (r.t == tv.best_t && pi < tv.best_prim)) {
             tv.best_t = r.t;

@@ -25,6 +25,7 @@ struct Call {
     double a, b, r;
 };
 static std::vector<Call> *sink = nullptr;
+static std::vector<double> *seg_sink = nullptr; // lane_emul_trace_segments: {sample, o, d, t, prim} per segment
 static int cur_sample = 0;
 static inline double rec(int fn, double a, double b, double r) {
     if (sink) sink->push_back(Call{cur_sample, fn, a, b, r});
@@ -147,6 +148,10 @@ void run(const RtLaunch &L, int x0, int y0, int x1, int y1, double *out, double 
                         } else {
                             rtl::leaf_step<G, M, T>(L, &ps, tv, st, &cnt[3]);
                         }
+                    }
+                    if (lane_trace::seg_sink) {
+                        const double row[9] = {(double)s, ps.o.x, ps.o.y, ps.o.z, ps.d.x, ps.d.y, ps.d.z, tv.best_t, (double)tv.best_prim};
+                        lane_trace::seg_sink->insert(lane_trace::seg_sink->end(), row, row + 9);
                     }
                     if (rtl::finish_segment<G, M, T>(L, &ps, tv, &rad)) break;
                 }
@@ -370,6 +375,23 @@ extern "C" long lane_emul_trace_pixel(rt_scene *s, const rt_camera *cam, int W, 
         out[5 * i + 4] = calls[(size_t)i].r;
     }
     return (long)calls.size();
+}
+
+// The segments of one pixel's samples as the lane program walks them: rows of {sample, o[3], d[3], t of the nearest hit (inf: none),
+// prim}; returns the number of segments (may exceed max_rows: then only the first are stored)
+extern "C" long lane_emul_trace_segments(rt_scene *s, const rt_camera *cam, int W, int H, int spp, int max_depth, uint64_t seed, int x, int y,
+                                         double *out, long max_rows) {
+    std::vector<double> rows;
+    std::vector<double> img((size_t)W * (size_t)H * 3);
+    unsigned long long cnt[5];
+    int hw = 0;
+    lane_trace::seg_sink = &rows;
+    const int rc = lane_emul_render(s, cam, W, H, spp, max_depth, seed, x, y, x + 1, y + 1, img.data(), nullptr, -1, -1, cnt, &hw);
+    lane_trace::seg_sink = nullptr;
+    if (rc != 0) return -1;
+    const long n = (long)(rows.size() / 9);
+    for (long i = 0; i < n && i < max_rows; ++i) std::memcpy(out + 9 * i, rows.data() + 9 * (size_t)i, 9 * sizeof(double));
+    return n;
 }
 
 // sensitivity probe: log's result off by one ulp for about one argument in n (0: never) -- what a device libm does to an image

@@ -94,6 +94,15 @@ def load(name):
         n = _LIB.lane_emul_trace_pixel(scene._h, C.addressof(cam.c), W, H, spp, max_depth, seed, x, y, out.ctypes.data_as(_DP), max_calls)
         assert 0 <= n <= max_calls, n
         return out[:n]
+    _LIB.lane_emul_trace_segments.restype = C.c_long
+    _LIB.lane_emul_trace_segments.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, _DP, C.c_long]
+
+    def trace_segments(scene, cam, W, H, spp, max_depth, seed, x, y, max_rows=1 << 16):
+        """the segments of pixel (x, y)'s samples as the lane program walks them -> (n, 9) array of {sample, o[3], d[3], t (inf: no hit), prim}"""
+        out = np.zeros((max_rows, 9))
+        n = _LIB.lane_emul_trace_segments(scene._h, C.addressof(cam.c), W, H, spp, max_depth, seed, x, y, out.ctypes.data_as(_DP), max_rows)
+        assert 0 <= n <= max_rows, n
+        return out[:n]
     _LIB.lane_emul_div3.argtypes = [C.c_long, _DP, _DP, _DP]
     _LIB.lane_emul_sphere_roots.argtypes = [C.c_long, _DP, _DP, _DP, _DP]
     _LIB.lane_emul_sphere_t_world.argtypes = [C.c_long, _DP, _DP, _DP, _DP]
@@ -132,7 +141,7 @@ def load(name):
     ns = types.SimpleNamespace(render=render, ball_check=ball_check, medium_forms=medium_forms, lds_layout=lds_layout, div3=div3,
                                sphere_roots=sphere_roots, sphere_t_world=sphere_t_world, rng_forms=rng_forms,
                                device_math=bool(_LIB.lane_emul_device_math()), set_rcp_mode=_LIB.lane_emul_set_rcp_mode,
-                               rcp_calls=lambda: int(_LIB.lane_emul_rcp_calls()), trace_pixel=trace_pixel, world_hit=world_hit, set_log_perturbation=_LIB.lane_emul_set_log_perturbation, name=name)
+                               rcp_calls=lambda: int(_LIB.lane_emul_rcp_calls()), trace_pixel=trace_pixel, trace_segments=trace_segments, world_hit=world_hit, set_log_perturbation=_LIB.lane_emul_set_log_perturbation, name=name)
     return ns
 
 
