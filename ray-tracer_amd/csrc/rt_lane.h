@@ -584,11 +584,13 @@ RT_HD bool ref_box_hit(const double *b, V3 o, V3 d) { // b: lo[3], hi[3]
            ref_slab(b[2], b[5], o.z, d.z, &tmin, &tmax);
 }
 // the boxes of a chain's levels, each against the ray in the frame above the level (chain_down's arithmetic level by level)
+// (out of line, and WITHOUT the launch descriptor: a by-value kernel argument whose address reaches a real call is copied to
+// scratch memory at kernel entry and read from there ever after -- measured: cornell 138 -> 184 ms)
 template <bool DEEP>
-RT_COLD bool chain_boxes_admit(const RtLaunch &L, uint32_t first, uint32_t len, uint32_t tmask, V3 o, V3 d) {
+RT_COLD bool chain_boxes_admit(const RtXform *xforms, uint32_t first, uint32_t len, uint32_t tmask, V3 o, V3 d) {
     for (uint32_t i = 0; i < len; ++i) {
         if (!DEEP && i >= (uint32_t)RT_MAX_CHAIN) break;
-        const RtXform &X = rec_at(L.xforms, first + i);
+        const RtXform &X = rec_at(xforms, first + i);
         if (X.box[0] == X.box[0] && !ref_box_hit(X.box, o, d)) return false;
         if (i < (uint32_t)RT_MAX_CHAIN && ((tmask >> i) & 1u)) {
             o = mk(o.x + X.inv[3], o.y + X.inv[7], o.z + X.inv[11]);
@@ -662,7 +664,7 @@ RT_HD bool medium_general_hit(const RtLaunch &L, const RtPrimGeo &G, V3 o, V3 d,
                 hit = shape_hit<true>(kw & 0xFFu, rec_at(L.prim_geo, ci), co, cd, uv, &cr);
             }
             // (the boundary's own nodes -- a Cube, a node of sprites -- keep boxes too)
-            if (hit && zd && !chain_boxes_admit<true>(L, cf, cl, cm, ro, d)) hit = false;
+            if (hit && zd && !chain_boxes_admit<true>(L.xforms, cf, cl, cm, ro, d)) hit = false;
             if (hit && (!have || cr.t < best.t)) {
                 chain_up<true>(L, cf, cl, cm, &cr);
                 best = cr;
@@ -753,23 +755,28 @@ RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx
     return false;
 }
 
-// A hit of primitive `pi` on a segment whose direction is (all but) parallel to an axis plane: would the reference's boxes above the
-// primitive have let the ray through (see ref_box_hit)?  Out of line: hardly ever called.
+// A hit of primitive `pi` on a segment whose direction is (all but) parallel to an axis plane: would the reference's boxes
+// above the primitive have let the ray through (see ref_box_hit)?  Hardly ever called; the work is out of line.
+// a sprite of the world's list under a pure translation (centre c): the 8 corners (+-r, +-r, +-r) through M are +-r + c
+RT_COLD bool sphere_box_admits(double cx, double cy, double cz, double radius, V3 o, V3 d) {
+    const double r = fabs(radius);
+    double tmin = 0.0, tmax = RTL_INF;
+    return ref_slab(-r + cx, r + cx, o.x, d.x, &tmin, &tmax) && ref_slab(-r + cy, r + cy, o.y, d.y, &tmin, &tmax) &&
+           ref_slab(-r + cz, r + cz, o.z, d.z, &tmin, &tmax);
+}
 template <bool GENERAL, int MEDIUM>
-RT_COLD bool own_boxes_admit(const RtLaunch &L, uint32_t pi, V3 o, V3 d) {
-    const RtPrimGeo &G = rec_at(L.prim_geo, pi);
+RT_HD bool own_boxes_admit(const RtLaunch &L, uint32_t pi, V3 o, V3 d) {
     uint32_t kw = (uint32_t)RT_PRIM_SPHERE_T;
     if (GENERAL || MEDIUM) kw = rec_at(L.prim_meta, pi).kind;
     const uint32_t kind = kw & 0xFFu;
     if (kind == RT_PRIM_SPHERE_T || kind == RT_PRIM_MEDIUM_T) {
-        // a sprite of the world's list under a pure translation: the 8 corners (+-r, +-r, +-r) through M are +-r + c
-        const double r = fabs(G.g[3]);
-        double tmin = 0.0, tmax = RTL_INF;
-        return ref_slab(-r + G.g[0], r + G.g[0], o.x, d.x, &tmin, &tmax) && ref_slab(-r + G.g[1], r + G.g[1], o.y, d.y, &tmin, &tmax) &&
-               ref_slab(-r + G.g[2], r + G.g[2], o.z, d.z, &tmin, &tmax);
+        const RtPrimGeo &G = (GENERAL || MEDIUM) ? rec_at(L.prim_geo, pi) : L.prim_geo[pi];
+        return sphere_box_admits(G.g[0], G.g[1], G.g[2], G.g[3], o, d);
     }
-    return chain_boxes_admit<(MEDIUM >= 2)>(L, rec_at(L.prim_meta, pi).xform, (kw >> RT_META_CHAIN_SHIFT) & 0xFu,
-                                            (kw >> RT_META_TMASK_SHIFT) & 0xFu, o, d);
+    if (GENERAL || MEDIUM)
+        return chain_boxes_admit<(MEDIUM >= 2)>(L.xforms, rec_at(L.prim_meta, pi).xform, (kw >> RT_META_CHAIN_SHIFT) & 0xFu,
+                                                (kw >> RT_META_TMASK_SHIFT) & 0xFu, o, d);
+    return true;
 }
 
 // The hit record of primitive `pi` at the parameter t the traversal found (shading).  The same arithmetic as the full test
