@@ -559,10 +559,11 @@ RT_HD void chain_up_point(const RtLaunch &L, uint32_t first, uint32_t len, uint3
 // above the primitive -- each object's OWN box (RtXform::box), i.e. the answer of every tree in which that object sits in a node
 // of its own; where the reference's random trees disagree with one another (a box shared with a sibling can be larger) this is
 // one of their answers.  For any other ray the boxes admit what the primitive accepts, so the gate only decides who pays.
-// near_axis: some component is zero or below 2^-20 of the largest (compared through the exponent fields)
+// near_axis: some component is zero or below 2^-30 of the largest (compared through the exponent fields; the rays in
+// question have components of exactly 0 or ~1e-17 of the others, a random direction qualifies once in ~1e9)
 RT_HD bool near_axis(V3 d) {
     const uint32_t ex = RT_HI32(d.x) & 0x7FFFFFFFu, ey = RT_HI32(d.y) & 0x7FFFFFFFu, ez = RT_HI32(d.z) & 0x7FFFFFFFu;
-    return umin(umin(ex, ey), ez) + (20u << 20) <= umax(umax(ex, ey), ez);
+    return umin(umin(ex, ey), ez) + (30u << 20) <= umax(umax(ex, ey), ez);
 }
 // AxisAlignedBoundingBox::hit (src/optimize.rs:61-82): t in [0, inf), the reference's selects and their NaN behaviour
 RT_HD bool ref_slab(double lo, double hi, double o, double d, double *tmin, double *tmax) { // one axis of the loop
@@ -938,11 +939,9 @@ RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack
     const double a = dot(d, d);
     tv.r2a = world_roots_rcp(L, o, a);
     sc.r2a = tv.r2a;
-    const bool zd = near_axis(d);
     for (int32_t pi = 0; pi < L.n_hoisted; ++pi) {
         Rec r;
         if (prim_hit<GENERAL, MEDIUM, false>(L, (uint32_t)pi, o, d, a, sc, &r, false)) {
-            if (zd && !own_boxes_admit<GENERAL, MEDIUM>(L, (uint32_t)pi, o, d)) continue; // (hardly ever: see ref_box_hit)
             if (r.t < tv.best_t) { // ascending prim id: ties keep the lower id
                 tv.best_t = r.t;
                 tv.best_prim = (uint32_t)pi;
@@ -952,6 +951,24 @@ RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack
     tv.best32 = up32(tv.best_t);
     tv.sp = 0;
     tv.cur = L.root;
+    // A segment that runs (all but) IN an axis plane is the one kind of ray for which the reference's binary64 boxes are not
+    // result-neutral (see ref_box_hit): it does not walk the culling structure at all.  Every leaf prim is tested in turn and a
+    // hit counts only if the reference's own boxes above that prim admit the ray; the lane is DONE at once.  About one
+    // segment in 1e9 of an ordinary scene; nearly all of an edge-running path in a scene scaled up 1e8-fold.
+    if (near_axis(d)) {
+        tv.best_t = RTL_INF;
+        tv.best_prim = 0xFFFFFFFFu;
+        for (int32_t pi = 0; pi < L.n_prims; ++pi) {
+            Rec r;
+            if (prim_hit<GENERAL, MEDIUM, false>(L, (uint32_t)pi, o, d, a, sc, &r, false) && r.t < tv.best_t &&
+                own_boxes_admit<GENERAL, MEDIUM>(L, (uint32_t)pi, o, d)) {
+                tv.best_t = r.t;
+                tv.best_prim = (uint32_t)pi;
+            }
+        }
+        tv.best32 = up32(tv.best_t);
+        tv.cur = Stack::Ref::kDone;
+    }
 }
 
 // one inner-node step (tv.cur is an inner node reference).  `nodes` is the node array (LDS copy or global).
@@ -1043,8 +1060,7 @@ RT_HD void trav_leaf_step(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, S
     const uint32_t pi = tv.cur & Stack::Ref::kMask;
     const double a = dot(d, d);
     Rec r;
-    if (prim_hit<GENERAL, MEDIUM, false>(L, pi, o, d, a, sc, &r, false) &&
-        !(near_axis(d) && !own_boxes_admit<GENERAL, MEDIUM>(L, pi, o, d))) { // (the boxes: hardly ever, see ref_box_hit)
+    if (prim_hit<GENERAL, MEDIUM, false>(L, pi, o, d, a, sc, &r, false)) {
         // nearest t; exact ties go to the lower prim id, whatever the visiting order
         if (r.t < tv.best_t || (r.t == tv.best_t && pi < tv.best_prim)) {
             tv.best_t = r.t;
