@@ -250,7 +250,7 @@ int rt_scene_commit(rt_scene *s, int device) {
         if ((rc = upload(s->flat.prim_meta, &s->d_prim_meta, &total))) return rc;
         if ((rc = upload(s->flat.prim_geo, &s->d_prim_geo, &total))) return rc;
         if ((rc = upload(s->flat.prim_extra, &s->d_prim_extra, &total))) return rc;
-        if ((rc = upload(s->flat.xforms, &s->d_xforms, &total))) return rc;
+        if ((rc = upload(s->flat.xform_store, &s->d_xforms, &total))) return rc; // boxes in reverse, then the records
         if ((rc = upload(s->flat.materials, &s->d_materials, &total))) return rc;
         if ((rc = upload(s->flat.textures, &s->d_textures, &total))) return rc;
         if ((rc = upload(s->flat.image_blob, &s->d_blob, &total))) return rc;
@@ -303,7 +303,7 @@ static void fill_launch(const rt_scene *s, const rt_camera *cam, const rt_render
     L->prim_meta = (const RtPrimMeta *)s->d_prim_meta;
     L->prim_geo = (const RtPrimGeo *)s->d_prim_geo;
     L->prim_extra = (const RtPrimExtra *)s->d_prim_extra;
-    L->xforms = (const RtXform *)s->d_xforms;
+    L->xforms = s->d_xforms ? (const RtXform *)((const unsigned char *)s->d_xforms + s->flat.xform_store_offset()) : nullptr;
     L->materials = (const RtMaterial *)s->d_materials;
     L->textures = (const RtTexture *)s->d_textures;
     L->image_blob = (const uint8_t *)s->d_blob;
@@ -960,6 +960,7 @@ int rt_scene_hash(const rt_scene *s, uint64_t *out) {
     eat(f.prim_geo.data(), f.prim_geo.size() * sizeof(RtPrimGeo));
     eat(f.prim_extra.data(), f.prim_extra.size() * sizeof(RtPrimExtra));
     eat(f.xforms.data(), f.xforms.size() * sizeof(RtXform));
+    eat(f.xform_boxes.data(), f.xform_boxes.size() * sizeof(RtXformBox));
     for (const RtMaterial &m : f.materials) { // field by field: the struct has padding
         eat(&m.kind, sizeof m.kind);
         eat(&m.tex, sizeof m.tex);

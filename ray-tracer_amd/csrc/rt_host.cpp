@@ -251,9 +251,6 @@ void make_xform(const double M[16], const double Minv[16], RtXform *x) {
             x->m[r * 4 + c] = M[c * 4 + r];
             x->inv[r * 4 + c] = Minv[c * 4 + r];
         }
-    x->box[0] = std::numeric_limits<double>::quiet_NaN(); // no reference box (set_ref_box)
-    for (int i = 1; i < 6; ++i) x->box[i] = 0.0;
-    x->pad_[0] = x->pad_[1] = 0.0;
 }
 
 // x' = m0*x + m4*y + m8*z + m12*w, evaluated left to right (src/vec4.rs:78-91)
@@ -725,12 +722,14 @@ uint32_t push_chain(FlatScene &fs, const std::vector<Link> &chain) {
     for (const Link &l : chain) {
         RtXform x;
         make_xform(l.M, l.Minv, &x);
+        RtXformBox b{{std::numeric_limits<double>::quiet_NaN(), 0.0, 0.0}, {0.0, 0.0, 0.0}}; // no reference box
         if (l.has_box)
             for (int i = 0; i < 3; ++i) {
-                x.box[i] = l.box.lo[i];
-                x.box[3 + i] = l.box.hi[i];
+                b.lo[i] = l.box.lo[i];
+                b.hi[i] = l.box.hi[i];
             }
         fs.xforms.push_back(x);
+        fs.xform_boxes.push_back(b);
     }
     return first;
 }
@@ -989,6 +988,13 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
     if (most > (size_t)RT_MAX_RECORDS || fs.image_blob.size() >= ((size_t)1 << 32)) {
         if (err) *err = "more than 2^24 records in one scene array (prims, transforms, materials, textures, nodes) or 4 GiB of texels";
         return RT_ERR_UNSUPPORTED;
+    }
+    // what the device (and the CPU harness of the tests) reads: the boxes in reverse, then the transform records (RtXformBox)
+    fs.xform_store.assign(fs.xforms.size() * (sizeof(RtXformBox) + sizeof(RtXform)) / sizeof(double), 0.0);
+    for (size_t i = 0; i < fs.xforms.size(); ++i) {
+        std::memcpy(fs.xform_store.data() + (fs.xforms.size() - 1 - i) * (sizeof(RtXformBox) / sizeof(double)), &fs.xform_boxes[i], sizeof(RtXformBox));
+        std::memcpy(fs.xform_store.data() + fs.xforms.size() * (sizeof(RtXformBox) / sizeof(double)) + i * (sizeof(RtXform) / sizeof(double)), &fs.xforms[i],
+                    sizeof(RtXform));
     }
     *out = std::move(fs);
     return RT_OK;

@@ -68,6 +68,13 @@ struct FlatScene {
     std::vector<Aabb> prim_bounds;
     int n_hoisted = 0;
     std::vector<RtXform> xforms;
+    std::vector<RtXformBox> xform_boxes; // parallel to xforms
+    // {boxes in reverse, xforms}: the memory image rtl::chain_boxes_admit expects around the transform array
+    std::vector<double> xform_store;
+    size_t xform_store_offset() const { return xforms.size() * sizeof(RtXformBox); } // bytes from the store's start to xforms[0]
+    const RtXform *xforms_in_store() const {
+        return xform_store.empty() ? nullptr : reinterpret_cast<const RtXform *>(reinterpret_cast<const unsigned char *>(xform_store.data()) + xform_store_offset());
+    }
     std::vector<RtMaterial> materials;
     std::vector<RtTexture> textures;
     std::vector<uint8_t> image_blob;

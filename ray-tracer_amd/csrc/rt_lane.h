@@ -556,7 +556,7 @@ RT_HD void chain_up_point(const RtLaunch &L, uint32_t first, uint32_t len, uint3
 // inclusively (src/geometry.rs:153-180).  Seen on rays that leave a cube's face ALONG the face, and then run along its edges,
 // after the degenerate refraction of scenes scaled up 1e8-fold (profiles/r04_boundary_plane_probe.json).  So a hit found on a
 // segment whose direction is that close to an axis plane is put through the binary64 boxes the reference keeps for the objects
-// above the primitive -- each object's OWN box (RtXform::box), i.e. the answer of every tree in which that object sits in a node
+// above the primitive -- each object's OWN box (RtXformBox), i.e. the answer of every tree in which that object sits in a node
 // of its own; where the reference's random trees disagree with one another (a box shared with a sibling can be larger) this is
 // one of their answers.  For any other ray the boxes admit what the primitive accepts, so the gate only decides who pays.
 // near_axis: some component is zero or below 2^-30 of the largest (compared through the exponent fields; the rays in
@@ -579,10 +579,10 @@ RT_HD bool ref_slab(double lo, double hi, double o, double d, double *tmin, doub
     *tmax = t1 < *tmax ? t1 : *tmax;
     return !(*tmax <= *tmin);
 }
-RT_HD bool ref_box_hit(const double *b, V3 o, V3 d) { // b: lo[3], hi[3]
+RT_HD bool ref_box_hit(const double *lo, const double *hi, V3 o, V3 d) {
     double tmin = 0.0, tmax = RTL_INF;
-    return ref_slab(b[0], b[3], o.x, d.x, &tmin, &tmax) && ref_slab(b[1], b[4], o.y, d.y, &tmin, &tmax) &&
-           ref_slab(b[2], b[5], o.z, d.z, &tmin, &tmax);
+    return ref_slab(lo[0], hi[0], o.x, d.x, &tmin, &tmax) && ref_slab(lo[1], hi[1], o.y, d.y, &tmin, &tmax) &&
+           ref_slab(lo[2], hi[2], o.z, d.z, &tmin, &tmax);
 }
 // the boxes of a chain's levels, each against the ray in the frame above the level (chain_down's arithmetic level by level)
 // (out of line, and WITHOUT the launch descriptor: a by-value kernel argument whose address reaches a real call is copied to
@@ -592,7 +592,8 @@ RT_COLD bool chain_boxes_admit(const RtXform *xforms, uint32_t first, uint32_t l
     for (uint32_t i = 0; i < len; ++i) {
         if (!DEEP && i >= (uint32_t)RT_MAX_CHAIN) break;
         const RtXform &X = rec_at(xforms, first + i);
-        if (X.box[0] == X.box[0] && !ref_box_hit(X.box, o, d)) return false;
+        const RtXformBox &B = reinterpret_cast<const RtXformBox *>(xforms)[-1 - (int32_t)(first + i)]; // rt_types.h
+        if (B.lo[0] == B.lo[0] && !ref_box_hit(B.lo, B.hi, o, d)) return false;
         if (i < (uint32_t)RT_MAX_CHAIN && ((tmask >> i) & 1u)) {
             o = mk(o.x + X.inv[3], o.y + X.inv[7], o.z + X.inv[11]);
         } else {
@@ -955,6 +956,7 @@ RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack
     // result-neutral (see ref_box_hit): it does not walk the culling structure at all.  Every leaf prim is tested in turn and a
     // hit counts only if the reference's own boxes above that prim admit the ray; the lane is DONE at once.  About one
     // segment in 1e9 of an ordinary scene; nearly all of an edge-running path in a scene scaled up 1e8-fold.
+#if !defined(RT_NO_CAREFUL)
     if (near_axis(d)) {
         tv.best_t = RTL_INF;
         tv.best_prim = 0xFFFFFFFFu;
@@ -969,6 +971,7 @@ RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack
         tv.best32 = up32(tv.best_t);
         tv.cur = Stack::Ref::kDone;
     }
+#endif
 }
 
 // one inner-node step (tv.cur is an inner node reference).  `nodes` is the node array (LDS copy or global).

@@ -99,14 +99,18 @@ struct alignas(16) RtPrimExtra {
 struct alignas(16) RtXform {
     double m[12];
     double inv[12];
-    // The reference's own bounding box of the object this level belongs to, in the frame ABOVE the level (the 8 transformed
-    // corners of the inner bound, src/optimize.rs:128-241) -- present when that object is the child of a
-    // BoundingVolumeHierarchyNode (a sprite of the world or of a node geometry, a face of a Cube), whose walk tests it in
-    // binary64 (src/optimize.rs:61-82,469-498).  box[0] is NaN otherwise (a TransformedGeometry: nobody tests its bound).
-    // Read only by rtl::chain_boxes_admit, for segments whose direction has an exactly-zero component.
-    double box[6]; // lo[3], hi[3]
-    double pad_[2];
-}; // 256 B
+}; // 192 B
+// The reference's own bounding box of the object a transform level belongs to, in the frame ABOVE the level (the 8
+// transformed corners of the inner bound, src/optimize.rs:128-241) -- present when that object is the child of a
+// BoundingVolumeHierarchyNode (a sprite of the world or of a node geometry, a face of a Cube), whose walk tests it in binary64
+// (src/optimize.rs:61-82,469-498); lo[0] is NaN otherwise (a TransformedGeometry: nobody tests its bound).  Read only by
+// rtl::chain_boxes_admit, for segments that run (all but) in an axis plane.  The boxes live in FRONT of the transform array, in
+// reverse: the box of xforms[i] is ((const RtXformBox *)xforms)[-1 - i] -- no kernel argument of their own, and the transform
+// records keep the stride and alignment they were measured with (as a 256-byte record with the box inside, the hot `inv`
+// halves sat in every other 128-byte line and the Cornell box lost 6 %).
+struct RtXformBox {
+    double lo[3], hi[3];
+}; // 48 B
 
 struct alignas(16) RtMaterial {
     uint32_t kind;

@@ -184,7 +184,7 @@ extern "C" int lane_emul_render(rt_scene *s, const rt_camera *cam, int W, int H,
     L.prim_meta = s->flat.prim_meta.data();
     L.prim_geo = s->flat.prim_geo.data();
     L.prim_extra = s->flat.prim_extra.data();
-    L.xforms = s->flat.xforms.data();
+    L.xforms = s->flat.xforms_in_store();
     L.materials = s->flat.materials.data();
     L.textures = s->flat.textures.data();
     L.image_blob = s->flat.image_blob.data();
