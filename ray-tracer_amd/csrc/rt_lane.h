@@ -760,11 +760,14 @@ RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx
 // A hit of primitive `pi` on a segment whose direction is (all but) parallel to an axis plane: would the reference's boxes
 // above the primitive have let the ray through (see ref_box_hit)?  Hardly ever called; the work is out of line.
 // a sprite of the world's list under a pure translation (centre c): the 8 corners (+-r, +-r, +-r) through M are +-r + c
-RT_COLD bool sphere_box_admits(double cx, double cy, double cz, double radius, V3 o, V3 d) {
+RT_HD bool sphere_box_admits(double cx, double cy, double cz, double radius, V3 o, V3 d) {
     const double r = fabs(radius);
     double tmin = 0.0, tmax = RTL_INF;
     return ref_slab(-r + cx, r + cx, o.x, d.x, &tmin, &tmax) && ref_slab(-r + cy, r + cy, o.y, d.y, &tmin, &tmax) &&
            ref_slab(-r + cz, r + cz, o.z, d.z, &tmin, &tmax);
+}
+RT_COLD bool sphere_box_admits_cold(double cx, double cy, double cz, double radius, V3 o, V3 d) {
+    return sphere_box_admits(cx, cy, cz, radius, o, d);
 }
 template <bool GENERAL, int MEDIUM>
 RT_HD bool own_boxes_admit(const RtLaunch &L, uint32_t pi, V3 o, V3 d) {
@@ -773,7 +776,8 @@ RT_HD bool own_boxes_admit(const RtLaunch &L, uint32_t pi, V3 o, V3 d) {
     const uint32_t kind = kw & 0xFFu;
     if (kind == RT_PRIM_SPHERE_T || kind == RT_PRIM_MEDIUM_T) {
         const RtPrimGeo &G = (GENERAL || MEDIUM) ? rec_at(L.prim_geo, pi) : L.prim_geo[pi];
-        return sphere_box_admits(G.g[0], G.g[1], G.g[2], G.g[3], o, d);
+        // (the spheres-only family has no other real call with arguments on the stack: inline there, it runs without scratch memory)
+        return (GENERAL || MEDIUM) ? sphere_box_admits_cold(G.g[0], G.g[1], G.g[2], G.g[3], o, d) : sphere_box_admits(G.g[0], G.g[1], G.g[2], G.g[3], o, d);
     }
     if (GENERAL || MEDIUM)
         return chain_boxes_admit<(MEDIUM >= 2)>(L.xforms, rec_at(L.prim_meta, pi).xform, (kw >> RT_META_CHAIN_SHIFT) & 0xFu,
@@ -902,12 +906,18 @@ RT_HD void trav_pop(Trav &tv, Stack &st) {
 // test (the rule the exact zeros of a direction have always followed, see below) -- conservative, and when all three
 // components are that small the segment simply walks without culling.  Nothing changes for any other segment.
 // binary32 constants of a segment's ray (what a traversal needs besides o, d and the best hit so far)
-RT_HD void trav_ray_constants(const RtLaunch &L, V3 o, V3 d, Trav &tv) {
+// Returns true for a segment that runs (all but) in an axis plane -- some |d_i| below 2^-29 of the largest, zero included: the
+// one kind of ray that does not use the culling structure at all (trav_begin, ref_box_hit).  The test rides on the rare branch
+// the reciprocals needed anyway: three binary32 operations per segment.
+RT_HD bool trav_ray_constants(const RtLaunch &L, V3 o, V3 d, Trav &tv) {
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
     tv.idx = rcp32((float)d.x);
     tv.idy = rcp32((float)d.y);
     tv.idz = rcp32((float)d.z);
-    if (fmaxf(fmaxf(fabsf(tv.idx), fabsf(tv.idy)), fabsf(tv.idz)) > 0x1p60f) { // (hardly ever)
+    bool near_plane = false;
+    const float big = fmaxf(fmaxf(fabsf(tv.idx), fabsf(tv.idy)), fabsf(tv.idz)), small = fminf(fminf(fabsf(tv.idx), fabsf(tv.idy)), fabsf(tv.idz));
+    if (__builtin_expect(!(big <= fminf(small * 0x1p29f, 0x1p60f)), 0)) { // (hardly ever; a NaN direction comes here too)
+        near_plane = !(big <= small * 0x1p29f);
         if (fabsf(tv.idx) > 0x1p60f) tv.idx = copysignf(__builtin_huge_valf(), tv.idx);
         if (fabsf(tv.idy) > 0x1p60f) tv.idy = copysignf(__builtin_huge_valf(), tv.idy);
         if (fabsf(tv.idz) > 0x1p60f) tv.idz = copysignf(__builtin_huge_valf(), tv.idz);
@@ -929,17 +939,56 @@ RT_HD void trav_ray_constants(const RtLaunch &L, V3 o, V3 d, Trav &tv) {
     tv.ox = (f32_bits(tv.idx) >> 31) * flip;
     tv.oy = (f32_bits(tv.idy) >> 31) * flip + ay;
     tv.oz = (f32_bits(tv.idz) >> 31) * flip + az;
+    return near_plane;
 }
 
 // start a segment: binary32 ray constants, hoisted prims, root
+// number of leaf prims: only the careful scan below reads it.  On the device it is re-read from the kernel-argument segment where
+// it is used (the launch descriptor is the kernel's first and only argument): a field read through the by-value argument is
+// loaded in the kernel's prologue and kept in an SGPR for the whole persistent loop, and one more live SGPR there is a spill to a
+// VGPR lane -- the 121st VGPR of the spheres-only kernel, which then no longer leaves room for the sums of the previous render
+// beside it (rt_kernels.hip kernarg_now, reduce_kernel)
+#if defined(__HIP_DEVICE_COMPILE__)
+RT_HD int32_t launch_n_prims(const RtLaunch &) {
+    const __attribute__((address_space(4))) RtLaunch *p = (const __attribute__((address_space(4))) RtLaunch *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p->n_prims;
+}
+#else
+RT_HD int32_t launch_n_prims(const RtLaunch &L) { return L.n_prims; }
+#endif
+
 template <bool GENERAL, int MEDIUM, class Stack>
 RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack &st) {
-    trav_ray_constants(L, o, d, tv);
+    const bool near_plane = trav_ray_constants(L, o, d, tv);
     tv.best_t = RTL_INF;
     tv.best_prim = 0xFFFFFFFFu;
     const double a = dot(d, d);
     tv.r2a = world_roots_rcp(L, o, a);
     sc.r2a = tv.r2a;
+    tv.sp = 0;
+#if !defined(RT_NO_CAREFUL)
+    // A segment that runs (all but) IN an axis plane is the one kind of ray for which the reference's binary64 boxes are not
+    // result-neutral (see ref_box_hit): it does not walk the culling structure at all.  Every leaf prim is tested in turn and a
+    // hit counts only if the reference's own boxes above that prim admit the ray; the lane is DONE at once.  About one
+    // segment in 1e9 of an ordinary scene; nearly all of an edge-running path in a scene scaled up 1e8-fold.
+    // (Inline: as a real call -- on the launch descriptor or on a private copy of it -- the descriptor, a by-value kernel
+    // argument, is copied to scratch memory and read from there ever after: Cornell box 138 -> 184 / 201 ms.)
+    if (__builtin_expect(near_plane, 0)) {
+        const int32_t n = launch_n_prims(L);
+        for (int32_t pi = 0; pi < n; ++pi) {
+            Rec r;
+            if (prim_hit<GENERAL, MEDIUM, false>(L, (uint32_t)pi, o, d, a, sc, &r, false) && r.t < tv.best_t &&
+                own_boxes_admit<GENERAL, MEDIUM>(L, (uint32_t)pi, o, d)) {
+                tv.best_t = r.t; // ascending prim id, strict <: ties keep the lower id
+                tv.best_prim = (uint32_t)pi;
+            }
+        }
+        tv.best32 = up32(tv.best_t);
+        tv.cur = Stack::Ref::kDone;
+        return;
+    }
+#endif
     for (int32_t pi = 0; pi < L.n_hoisted; ++pi) {
         Rec r;
         if (prim_hit<GENERAL, MEDIUM, false>(L, (uint32_t)pi, o, d, a, sc, &r, false)) {
@@ -950,28 +999,7 @@ RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack
         }
     }
     tv.best32 = up32(tv.best_t);
-    tv.sp = 0;
     tv.cur = L.root;
-    // A segment that runs (all but) IN an axis plane is the one kind of ray for which the reference's binary64 boxes are not
-    // result-neutral (see ref_box_hit): it does not walk the culling structure at all.  Every leaf prim is tested in turn and a
-    // hit counts only if the reference's own boxes above that prim admit the ray; the lane is DONE at once.  About one
-    // segment in 1e9 of an ordinary scene; nearly all of an edge-running path in a scene scaled up 1e8-fold.
-#if !defined(RT_NO_CAREFUL)
-    if (near_axis(d)) {
-        tv.best_t = RTL_INF;
-        tv.best_prim = 0xFFFFFFFFu;
-        for (int32_t pi = 0; pi < L.n_prims; ++pi) {
-            Rec r;
-            if (prim_hit<GENERAL, MEDIUM, false>(L, (uint32_t)pi, o, d, a, sc, &r, false) && r.t < tv.best_t &&
-                own_boxes_admit<GENERAL, MEDIUM>(L, (uint32_t)pi, o, d)) {
-                tv.best_t = r.t;
-                tv.best_prim = (uint32_t)pi;
-            }
-        }
-        tv.best32 = up32(tv.best_t);
-        tv.cur = Stack::Ref::kDone;
-    }
-#endif
 }
 
 // one inner-node step (tv.cur is an inner node reference).  `nodes` is the node array (LDS copy or global).

@@ -10,7 +10,7 @@ for round in $(seq $ROUNDS); do
    (cd $t && timeout -k 10 300 python3 bench.py --scene $sc --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null) | python3 -c "
 import sys,json
 d=json.loads([l for l in sys.stdin if l.startswith(chr(123))][-1]); r=d['roofline']
-print('round $round', '$(basename $t)', d['config']['workload'][:12], round(d['value'],1), 'Ms/s kernel_ms', round(r['kernel_ms'],2))"
+print('round $round', '$(basename $t)', d['config']['workload'][:12], round(d['value'],1), 'Ms/s kernel_ms', round(r['kernel_ms'],2), 'step_ms', round(d['ms_per_step'],2))"
   done
  done
 done
