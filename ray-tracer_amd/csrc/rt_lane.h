@@ -349,7 +349,6 @@ RT_HD bool sphere_t(V3 oc, V3 d, double a, double radius, double *t_out, double 
 // (tests/lane_emul.cpp defines RTL_LOG ... before this header to record the arguments a path passes to them)
 #if !defined(RTL_LOG)
 #define RTL_LOG(x) rtm::log(x)
-#define RTL_LOG_WITH(x, e) rtm::log_with(x, e)
 #define RTL_SIN(x) rtm::sin(x)
 #define RTL_ATAN2(y, x) rtm::atan2(y, x)
 #define RTL_ACOS(x) rtm::acos(x)
@@ -364,12 +363,6 @@ RT_COLD UV sphere_uv_cold(double qx, double qy, double qz) { // unitSphereUv, sr
     return r;
 }
 RT_COLD double log_cold(double x) { return RTL_LOG(x); }
-RT_COLD double log_with_cold(double x, double invc, double logc) { // the table entry fetched by the caller (rtm::log_fetch)
-    rtm::LogEntry e;
-    e.invc = invc;
-    e.logc = logc;
-    return RTL_LOG_WITH(x, e);
-}
 RT_COLD double checker_sine_cold(double u, double v) { // src/material.rs:238
     return RTL_SIN(2.0 * RTL_PI * 10.0 * u) * RTL_SIN(2.0 * RTL_PI * 10.0 * v);
 }
@@ -424,10 +417,6 @@ RT_HD void to_world(const RtXform &x, Rec *r) {
 template <bool RECORD>
 RT_HD bool medium_hit(V3 oc, V3 d, double radius, double neg_inv_density, uint64_t rng_base, uint32_t segment, uint32_t slot,
                       unsigned long long *draws, bool uv, Rec *r) {
-    // the free-flight draw is keyed (include/rt_rng.h), so it is known now: its logarithm's table entry is on its way while the
-    // boundary is intersected (rtm::log_fetch)
-    const double u01 = rt_u64_to_range01(rt_rng_keyed_from_base(rng_base, segment, slot));
-    const rtm::LogEntry le = rtm::log_fetch(u01);
     double a = dot(d, d);
     double t1;
     if (!sphere_t(oc, d, a, radius, &t1)) return false;
@@ -455,7 +444,7 @@ RT_HD bool medium_hit(V3 oc, V3 d, double radius, double neg_inv_density, uint64
         if (RECORD) sphere_finish(o2, d, radius, t2, uv, &r2);
         double inside = r2.t;
         ++*draws;
-        double distance = neg_inv_density * log_with_cold(u01, le.invc, le.logc);
+        double distance = neg_inv_density * log_cold(rt_u64_to_range01(rt_rng_keyed_from_base(rng_base, segment, slot)));
         if (distance > inside) return false;
         r->t = r1.t + distance;
         if (RECORD) {
@@ -468,7 +457,7 @@ RT_HD bool medium_hit(V3 oc, V3 d, double radius, double neg_inv_density, uint64
     }
     double inside = r1.t;
     ++*draws;
-    double distance = neg_inv_density * log_with_cold(u01, le.invc, le.logc);
+    double distance = neg_inv_density * log_cold(rt_u64_to_range01(rt_rng_keyed_from_base(rng_base, segment, slot)));
     if (distance > inside) return false;
     r->t = distance;
     if (RECORD) {

@@ -54,31 +54,7 @@ RTM_FN double nan_() { return from_bits(0x7FF8000000000000ull); }
 // ---------------------------------------------------------------------------------------------------------------------
 // log: glibc 2.35 sysdeps/ieee754/dbl-64/e_log.c (the table-driven algorithm of ARM's optimized routines), __log_fma
 // ---------------------------------------------------------------------------------------------------------------------
-// The table entry log (x) will read, fetched ahead of time: a caller that knows x long before it needs the logarithm (a medium's
-// free-flight draw is keyed, not sequential: it is known before the boundary is intersected) starts the load early and hides its
-// latency behind that work -- inside log () the load and its first use are back to back, and with a 217 KB node array washing
-// through the L1 the 2 KB table is an L2 access (book-two cover: +2 % when the load sat inside the function).
-struct LogEntry {
-    double invc, logc;
-};
-RTM_FN uint64_t log_normalised_bits(double x) { // ix of the main path: a subnormal argument is scaled into the normal range first
-    uint64_t ix = bits(x);
-    const uint32_t top = (uint32_t)(ix >> 48);
-    if (top - 0x0010u >= 0x7FF0u - 0x0010u && ix * 2 != 0 && !(top & 0x8000u) && (top & 0x7FF0u) != 0x7FF0u) {
-        ix = bits(x * 0x1p52);
-        ix -= 52ull << 52;
-    }
-    return ix;
-}
-RTM_FN LogEntry log_fetch(double x) {
-    const uint64_t tmp = log_normalised_bits(x) - 0x3FE6000000000000ull;
-    const uint32_t i = (uint32_t)(tmp >> 45) & 127u;
-    LogEntry e;
-    e.invc = rtm_log_tab[2 * i];
-    e.logc = rtm_log_tab[2 * i + 1];
-    return e;
-}
-RTM_FN double log_with(double x, LogEntry entry) { // log (x) given log_fetch (x)
+RTM_FN double log(double x) {
     const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
     const double A0 = -0x1.0000000000001p-1, A1 = 0x1.555555551305bp-2, A2 = -0x1.fffffffeb4590p-3,
                  A3 = 0x1.999b324f10111p-3, A4 = -0x1.55575e506c89fp-3;
@@ -117,9 +93,10 @@ RTM_FN double log_with(double x, LogEntry entry) { // log (x) given log_fetch (x
         ix -= 52ull << 52;
     }
     const uint64_t tmp = ix - 0x3FE6000000000000ull;
+    const uint32_t i = (uint32_t)(tmp >> 45) & 127u;
     const int32_t k = (int32_t)((int64_t)tmp >> 52);
     const uint64_t iz = ix - (tmp & 0xFFF0000000000000ull);
-    const double invc = entry.invc, logc = entry.logc;
+    const double invc = rtm_log_tab[2 * i], logc = rtm_log_tab[2 * i + 1];
     const double z = from_bits(iz);
     const double r = fma_(z, invc, -1.0);
     const double kd = (double)k;
@@ -136,7 +113,6 @@ RTM_FN double log_with(double x, LogEntry entry) { // log (x) given log_fetch (x
     const double y = fma_(rr2, q, lo2);
     return y + hi;
 }
-RTM_FN double log(double x) { return log_with(x, log_fetch(x)); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // sin: glibc 2.35 sysdeps/ieee754/dbl-64/s_sin.c (IBM Accurate Mathematical Library), __sin_fma

@@ -32,10 +32,8 @@ static inline double rec(int fn, double a, double b, double r) {
     return r;
 }
 static int perturb_log = 0; // lane_emul_set_log_perturbation: move log's result by one ulp for about 1 argument in N (a stand-in for a libm that is not correctly rounded)
-static inline double t_log_of(double x, double r);
-static inline double t_log(double x) { return t_log_of(x, rtm::log(x)); }
-static inline double t_log_with(double x, rtm::LogEntry e) { return t_log_of(x, rtm::log_with(x, e)); } // the entry the caller fetched
-static inline double t_log_of(double x, double r) {
+static inline double t_log(double x) {
+    double r = rtm::log(x);
     if (perturb_log > 0) {
         uint64_t b;
         memcpy(&b, &x, sizeof b);
@@ -49,7 +47,6 @@ static inline double t_atan2(double y, double x) { return rec(2, y, x, rtm::atan
 static inline double t_acos(double x) { return rec(3, x, 0.0, rtm::acos(x)); }
 } // namespace lane_trace
 #define RTL_LOG(x) lane_trace::t_log(x)
-#define RTL_LOG_WITH(x, e) lane_trace::t_log_with(x, e)
 #define RTL_SIN(x) lane_trace::t_sin(x)
 #define RTL_ATAN2(y, x) lane_trace::t_atan2(y, x)
 #define RTL_ACOS(x) lane_trace::t_acos(x)
