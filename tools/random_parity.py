@@ -75,8 +75,26 @@ for seed in range(FIRST, FIRST + N):
         over_bar.append([seed, W, H, spp, mae, nbad])
         if GEN == "general":
             sys.exit(1)
+# A pixel that differs from the oracle may be one on which the oracle differs from ITSELF: the reference builds its trees with
+# random axes (src/optimize.rs:374-409) and for a ray lying in a box's boundary plane the boxes of a pair of siblings decide
+# otherwise than either's own (rt_lane.h ref_box_hit).  Every scene with differing pixels is rendered again under eight other
+# trees: a pixel whose kernel value is the oracle's under one of them is the reference's own tree dependence, not a deviation.
+explained, unexplained = [], []
+for seed in sorted({p[0] for p in differing}):
+    rng = np.random.default_rng(seed)
+    W, H, spp = int(rng.integers(24, 96)) * SCALE, int(rng.integers(16, 72)) * SCALE, int(rng.integers(2, 12)) * SCALE
+    d = make_scene(seed, W / H)
+    sc, cam = scenes.build_product(d, device=0)
+    img = sc.render(cam, W, H, spp, DEPTH, seed=seed)
+    others = [oracle.build_oracle(d, bvh_seed=t).render(W, H, spp, DEPTH, seed=seed, iterative=True, nthreads=threads) for t in range(1, 9)]
+    for p in differing:
+        if p[0] != seed:
+            continue
+        x, y = p[4], p[5]
+        (explained if any(np.array_equal(o[y, x], img[y, x]) for o in others) else unexplained).append(p)
 res = {"scenes": N, "first_seed": FIRST, "max_depth": DEPTH, "generator": GEN, "scale": SCALE, "of_them_with_deep_chains_and_nested_media": N // 2 if GEN == "general" else 0, "bit_identical_scenes": exact, "pixels": pixels, "pixels_differing_by_more_than_1e-12": bad_pixels,
        "worst_mean_abs_error": worst_mae, "worst_abs_diff": worst_max, "differing_pixels_per_scene_histogram": {str(k): v for k, v in sorted(hist.items())},
-       "scenes_over_the_bar": over_bar, "pixels_not_bit_identical": differing, "seconds": time.time() - t0, "bar": "mean abs error <= 1e-4 per scene"}
+       "scenes_over_the_bar": over_bar, "pixels_not_bit_identical": differing,
+       "of_them_equal_to_the_oracle_under_another_of_8_trees": len(explained), "of_them_unexplained": unexplained, "seconds": time.time() - t0, "bar": "mean abs error <= 1e-4 per scene"}
 print(res)
 json.dump(res, open(ROOT / "gpurun_out" / ("random_parity.json" if (FIRST, DEPTH, GEN) == (100, 40, "general") else f"random_parity_{GEN}_from_{FIRST}_depth_{DEPTH}" + (f"_x{SCALE}" if SCALE != 1 else "") + ".json"), "w"), indent=1)
