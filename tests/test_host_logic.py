@@ -22,22 +22,110 @@ def test_abi_exports_every_declared_symbol(rt):
     assert declared == set(rt.ABI), "python binding table and header disagree"
 
 
+def _c_type(decl: str) -> str:
+    """canonical spelling of a C parameter / return / field type (the declarator's name removed):
+    `const double M[16]` -> `*const f64`, `rt_scene *const *` -> `*const *mut rt_scene`, `unsigned flags` -> `u32` ..."""
+    decl = " ".join(decl.replace("*", " * ").split())
+    array = re.search(r"\[\s*\d*\s*\]$", decl) is not None
+    decl = re.sub(r"\s*\[\s*\d*\s*\]$", "", decl)
+    toks = decl.split()
+    base_words = {"const", "unsigned", "signed", "int", "char", "double", "float", "void", "size_t", "uint8_t", "uint32_t", "uint64_t", "int32_t",
+                  "int64_t", "long", "short", "struct"}
+    # drop the identifier: the last token when it is neither a type word, a `*`, nor a typedef name standing alone
+    if len(toks) > 1 and toks[-1] not in base_words and toks[-1] != "*" and not (toks[-2] in ("const",) and len(toks) == 2):
+        if not toks[-1].startswith("rt_") or toks[-2] in ("*",) or toks[-2].startswith("rt_") or toks[-2] in base_words:
+            toks = toks[:-1]
+    # split into the base type and the pointer levels (each with its own const-ness of the POINTEE)
+    first_star = toks.index("*") if "*" in toks else len(toks)
+    base, rest = toks[:first_star], toks[first_star:]
+    base_const = "const" in base
+    base = [t for t in base if t not in ("const", "struct")]
+    name = " ".join(base)
+    prim = {"int": "i32", "unsigned": "u32", "unsigned int": "u32", "uint32_t": "u32", "int32_t": "i32", "uint64_t": "u64", "int64_t": "i64",
+            "size_t": "usize", "double": "f64", "float": "f32", "char": "c_char", "uint8_t": "u8", "unsigned char": "u8", "void": "void"}
+    t = prim.get(name, name)
+    levels = []  # const-ness of each pointer level's pointee, innermost first
+    pointee_const = base_const
+    for tok in rest:
+        if tok == "*":
+            levels.append(pointee_const)
+            pointee_const = False
+        elif tok == "const":
+            pointee_const = True
+    if array:
+        levels.append(pointee_const)
+    for c in levels:
+        t = ("*const " if c else "*mut ") + t
+    return t
+
+
+def _rust_type(t: str) -> str:
+    t = " ".join(t.split())
+    m = re.fullmatch(r"\[(.+); (\d+)\]", t)
+    if m:
+        return "[%s; %s]" % (_rust_type(m.group(1)), m.group(2))
+    for ptr in ("*const ", "*mut "):
+        if t.startswith(ptr):
+            return ptr + _rust_type(t[len(ptr):])
+    return {"c_int": "i32", "c_uint": "u32", "c_double": "f64", "c_float": "f32", "c_void": "void", "c_char": "c_char"}.get(t, t)
+
+
+def _split_params(params: str):
+    params = params.strip()
+    if params in ("", "void"):
+        return []
+    return [p.strip() for p in params.split(",") if p.strip()]  # (Rust allows a trailing comma)
+
+
+def test_c_type_spelling():
+    assert _c_type("const double M[16]") == "*const f64" and _c_type("double out[6]") == "*mut f64"
+    assert _c_type("rt_scene *const *scenes") == "*const *mut rt_scene" and _c_type("const rt_scene *") == "*const rt_scene"
+    assert _c_type("unsigned flags") == "u32" and _c_type("size_t n_pixels") == "usize" and _c_type("const char *path") == "*const c_char"
+    assert _c_type("void *stream") == "*mut void" and _c_type("const void *p") == "*const void" and _c_type("uint64_t *out") == "*mut u64"
+    assert _c_type("int") == "i32" and _c_type("rt_scene *") == "*mut rt_scene" and _c_type("const uint8_t *rgb") == "*const u8"
+
+
 def test_rust_ffi_declares_every_entry_point():
-    """ray-tracer_amd/rust/src/ffi.rs (uncompilable here: no Rust toolchain) against include/rt_mi355x.h, mechanically:
-    the same set of functions, and the same field counts for the structs that cross the boundary"""
-    import re
-    from pathlib import Path
-    root = Path(__file__).resolve().parent.parent
-    header = re.sub(r"/\*.*?\*/", "", (root / "include" / "rt_mi355x.h").read_text(), flags=re.S)
+    """ray-tracer_amd/rust/src/ffi.rs (uncompilable here: no Rust toolchain) against include/rt_mi355x.h, mechanically -- the one
+    check that can stand in for `cargo check`: the same set of functions; for every function the same NUMBER of
+    parameters, the same TYPE in every position (c_int / c_uint / c_double / usize / u64 / *const T / *mut T, arrays decaying to
+    pointers) and the same return type; for every struct that crosses the boundary the same fields, in order, with the same types."""
+    header = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "rt_mi355x.h").read_text(), flags=re.S)
+    header = re.sub(r"//.*", "", header)
     declared = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", header))
-    ffi = (root / "ray-tracer_amd" / "rust" / "src" / "ffi.rs").read_text()
+    ffi = (ROOT / "ray-tracer_amd" / "rust" / "src" / "ffi.rs").read_text()
+    ffi = re.sub(r"//.*", "", ffi)
     bound = set(re.findall(r"pub fn (rt_[a-z0-9_]+)\s*\(", ffi))
     assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
+
+    c_protos = {name: (ret, params) for ret, name, params in
+                re.findall(r"^\s*([A-Za-z_][A-Za-z0-9_ \*]*?)\b(rt_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.M | re.S)}
+    assert set(c_protos) == declared, sorted(declared - set(c_protos))
+    r_protos = {name: (params, ret) for name, params, ret in
+                re.findall(r"pub fn (rt_[a-z0-9_]+)\s*\((.*?)\)\s*(?:->\s*([^;]+?))?\s*;", ffi, flags=re.S)}
+    assert set(r_protos) == declared
+    for name in sorted(declared):
+        c_ret, c_params = c_protos[name]
+        r_params, r_ret = r_protos[name]
+        c_types = [_c_type(p) for p in _split_params(c_params)]
+        r_types = [_rust_type(p.split(":", 1)[1]) for p in _split_params(r_params)]
+        assert c_types == r_types, (name, c_types, r_types)
+        c_r = _c_type(c_ret.strip() + " x")  # (a dummy declarator name, as for a parameter)
+        r_r = _rust_type(r_ret) if r_ret else "void"
+        assert c_r == r_r, (name, c_r, r_r)
+
     for struct in ("rt_camera", "rt_render_params", "rt_counters", "rt_launch_config", "rt_scene_info"):
         c_body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), header, flags=re.S).group(1)
-        c_fields = sum(len(decl.split(",")) for decl in re.findall(r"[a-z_0-9 ]+?\s+([a-z_0-9, \[\]]+);", c_body))
+        c_fields = []
+        for decl in [d.strip() for d in c_body.split(";") if d.strip()]:
+            m = re.fullmatch(r"(.+?)\s+([a-z_0-9, \[\]]+)", " ".join(decl.split()))
+            ctype, names = m.group(1), m.group(2)
+            for nm in [n.strip() for n in names.split(",")]:
+                arr = re.fullmatch(r"([a-z_0-9]+)\[(\d+)\]", nm)
+                base = _c_type(ctype + " x")
+                c_fields.append((arr.group(1), "[%s; %s]" % (base, arr.group(2))) if arr else (nm, base))
         r_body = re.search(r"pub struct %s \{(.*?)\n\}" % struct, ffi, flags=re.S).group(1)
-        r_fields = len(re.findall(r"pub [a-z_0-9]+:", r_body))
+        r_fields = [(n, _rust_type(t)) for n, t in re.findall(r"pub ([a-z_0-9]+):\s*([^,\n]+),", r_body)]
         assert c_fields == r_fields, (struct, c_fields, r_fields)
 
 
