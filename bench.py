@@ -191,8 +191,7 @@ def spawn_ranks(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
-    env.setdefault("OMP_NUM_THREADS", "4")
+    env.setdefault("OMP_NUM_THREADS", "4")  # (what RCCL needs is set by every rank itself: rank_environment)
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)  # stderr passes through
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
     for ln in r.stdout.splitlines():
@@ -206,8 +205,24 @@ def spawn_ranks(n):
     return r.returncode
 
 
+def rank_environment():
+    """What a rank needs in its environment, set by the rank ITSELF before torch (and with it the HIP runtime) is imported -- the
+    same for ranks started by the driver's `python -m torch.distributed.run ... bench.py` and for ranks started by spawn_ranks:
+    one environment for both launch paths.  HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver of this pool only supports dmabuf
+    IPC; without it sharing device memory between processes (RCCL's peer-to-peer transport) fails with
+    `hipIpcGetMemHandle: invalid argument`.  An operator's own setting wins."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def predicted_strong_scaling(n):
+    """profiles / tools/shard_scaling.py: speed-up over N = 1 predicted from per-shard kernel times measured on ONE MI355X (1/N
+    shard of the image, before the gather): a prediction printed beside the measurement, never instead of it"""
+    return {1: 1.0, 2: 1.97, 4: 3.81, 8: 7.09}.get(n)
+
+
 def main():
     a = parse()
+    rank_environment()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -356,15 +371,23 @@ def main():
     anatomy["render_kernel_ms"] = sc.last_kernel_ms()
 
     # per-launch kernel duration measured with HIP events on the launch stream: time each launch separately, untimed loop
-    per_launch = []
+    # ... and ONE render on its own, nothing beside it: render_kernel, then the sums of its sample records on the same stream
+    # (no following render to hide them behind): what a caller who renders a single image gets
+    per_launch, single = [], []
     for _ in range(max(1, min(a.steps, 3))):
-        stream = torch.cuda.current_stream().cuda_stream
-        sc.render_tiles_device(cam, W, H, spp, depth, a.seed, (rank, world), mine.data_ptr(), None, stream)
+        cur = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        sc.render_tiles_device(cam, W, H, spp, depth, a.seed, (rank, world), mine.data_ptr(), None, cur.cuda_stream)
+        e1.record(cur)
+        torch.cuda.synchronize()
         per_launch.append(sc.last_kernel_ms())
+        single.append(e0.elapsed_time(e1))
     kernel_avg_ms = float(np.mean(per_launch))
+    single_render_ms = float(np.mean(single))
     launch_cfg = sc.last_launch_config()
 
-    tmax = torch.tensor([dt, kernel_avg_ms], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt, kernel_avg_ms, single_render_ms], dtype=torch.float64, device=dev)
     per_rank = None
     if world > 1:
         if a.backend == "gloo":
@@ -374,6 +397,7 @@ def main():
         dist.gather_object(dict(anatomy, rank=rank, device=local_rank, tiles=n_tiles[rank]), per_rank, dst=0)
     dt = float(tmax[0])
     kernel_avg_ms = float(tmax[1])
+    single_render_ms = float(tmax[2])
 
     if rank == 0:
         total_samples = W * H * spp
@@ -419,21 +443,40 @@ def main():
                        "bvh_nodes": info["n_nodes"], "sharding": f"8x8 tiles, tile_id % {world}, one RCCL gather",
                        "library": rt.version(), "steps_pipelined_on_two_streams": bool(a.pipeline),
                        "sums_behind_the_next_render": bool(defer)},
+            # `value` is the pipelined figure (a step's sums run beside the next step's render); one image rendered alone:
+            "single_render_ms": single_render_ms, "single_render_msamples_per_s": total_samples / (single_render_ms * 1e-3) / 1e6,
+            "single_render_note": "one rt_render_tiles_device on its own (render_kernel + reduce_kernel on one stream, slowest rank), "
+                                  "without the gather / unpack / copy that `value` includes and without a following render to hide the sums",
             "roofline": roof, "wall_s": dt, "last_kernel_ms": last_kernel_ms,
             "step_anatomy_ms": per_rank if per_rank is not None else [dict(anatomy, rank=0, device=local_rank, tiles=n_tiles[0])],
         }
+        image_ok = True
         if (world > 1 and not a.no_check) or a.check:
             whole = sc.render(cam, W, H, spp, depth, a.seed)
             last = host_images[(step_no[0] - 1) & 1]
-            res["image_matches_single_gpu"] = bool(np.array_equal(last.numpy().reshape(H, W, 3), whole))
+            image_ok = bool(np.array_equal(last.numpy().reshape(H, W, 3), whole))
+            res["image_matches_single_gpu"] = image_ok
+        if per_rank is not None:
+            # where the time of a step goes on each rank, and how even the shards are (the slowest rank is the step)
+            rms = [r["render_ms"] for r in per_rank]
+            res["ranks"] = {"render_ms": {"min": min(rms), "max": max(rms), "mean": sum(rms) / len(rms), "spread": max(rms) - min(rms)},
+                            "gather_ms_rank0": per_rank[0].get("gather_ms"), "unpack_ms_rank0": per_rank[0].get("unpack_ms"),
+                            "d2h_ms_rank0": per_rank[0].get("d2h_ms"),
+                            "predicted_speedup_over_1_gpu": predicted_strong_scaling(world),
+                            "prediction_source": "tools/shard_scaling.py: per-shard kernel times on one MI355X, before the gather"}
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(desc, scene_words, W, H, spp, depth, a.seed, a.cpu_seconds, scenes)
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
+    else:
+        image_ok = True
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if not image_ok:  # the line above says so; the exit code does too (the launcher relays it)
+        print("[bench] the gathered image differs from a single-GPU render of the whole image", file=sys.stderr, flush=True)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

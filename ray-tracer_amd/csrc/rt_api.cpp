@@ -448,19 +448,20 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     const unsigned lds_share = (RT_LDS_PER_CU / groups_per_cu) & ~(RT_LDS_GRANULE - 1u);
     const int list = s->flat.n_list > 0; // the box list (< 1 KB) always lives in LDS
     const unsigned min_cap = swap ? (block >= 512u ? (unsigned)RT_SWAP_CAP : 32u) : 0u; // the node copy must leave room for this
-    const unsigned n_queues = rt_swap_queues(feat != 0u); // the general families keep a ray queue besides the three class queues
     const int ldsnodes = list || (!wide && node_bytes > 0 && !(no_lds && *no_lds == '1') &&
-                                  rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, node_bytes, min_cap, n_queues).total <= lds_share);
+                                  rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, node_bytes, min_cap).total <= lds_share);
     const unsigned in_lds = ldsnodes ? node_bytes : 0u;
-    const unsigned swap_cap = swap ? rt_swap_cap_that_fits((unsigned)L.stack_entries, block, entry_bytes, in_lds, groups_per_cu, n_queues) : 0u;
+    const unsigned swap_cap = swap ? rt_swap_cap_that_fits((unsigned)L.stack_entries, block, entry_bytes, in_lds, groups_per_cu) : 0u;
     L.swap_cap = (int)swap_cap;
-    const RtLdsLayout lay = rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, in_lds, swap ? rt_swap_cap_effective(block, swap_cap) : 0u, n_queues);
+    const RtLdsLayout lay = rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, in_lds, swap ? rt_swap_cap_effective(block, swap_cap) : 0u);
     if (!rt_lds_layout_aligned(lay)) return fail(RT_ERR_DEVICE, "internal: misaligned LDS layout");
     const unsigned lds_bytes = lay.total;
     if (lds_bytes > RT_LDS_PER_CU) return fail(RT_ERR_UNSUPPORTED, "the scene's traversal stack does not fit a CU's LDS");
     L.lds_bytes = lds_bytes;
-    if (const char *t = std::getenv("RT_TEST_LDS_SHORT")) // tests only: claim fewer bytes than the layout needs -> the kernel must refuse
+#if defined(RT_TEST_HOOKS) // librt_mi355x_testhooks.so only (Makefile): the shipped library reads no RT_TEST_* variable
+    if (const char *t = std::getenv("RT_TEST_LDS_SHORT")) // claim fewer bytes than the layout needs -> the kernel must refuse
         if (*t == '1') L.lds_bytes = lds_bytes - 64u;
+#endif
     const int lds_mode = (ldsnodes ? 1 : 0) | (swap ? 2 : 0) | (wide ? 4 : 0) | (list ? 8 : 0);
     int per_cu = 0, n_cu = 0, rc = 0;
     const unsigned occ_key = feat | (lens ? 32u : 0u) | (count ? 64u : 0u) | ((unsigned)lds_mode << 7); // feat uses bits 0-4
@@ -487,7 +488,9 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     L.watchdog_trips = 0u;
     if (count) {
         L.watchdog_trips = 1024u * (unsigned)(s->flat.nodes.size() + s->flat.prim_meta.size() + 64u);
-        if (const char *t = std::getenv("RT_TEST_WATCHDOG_TRIPS")) L.watchdog_trips = (unsigned)std::strtoul(t, nullptr, 10); // tests only
+#if defined(RT_TEST_HOOKS)
+        if (const char *t = std::getenv("RT_TEST_WATCHDOG_TRIPS")) L.watchdog_trips = (unsigned)std::strtoul(t, nullptr, 10);
+#endif
     }
     L.counters = count ? (RtCounters *)d_counters : nullptr;
     const int n_pass = (n_spp + chunk - 1) / chunk;

@@ -24,10 +24,13 @@
 //   is empty.  Scheduling never changes a result: each path consumes its own
 //   random stream (include/rt_rng.h) and every sample is an independent value.
 //   The traversal stack lives in LDS, [depth][thread], conflict-free ds_read/write_b32.
-//   Three kernel families share the code: spheres only (book-one: 125 VGPRs, 4 waves
-//   per SIMD, 512-thread groups), general prims without media / textures (Cornell box:
-//   157 VGPRs, 3 waves per SIMD as three 256-thread groups per CU) and the full general
-//   kernel (245 VGPRs, 2 waves per SIMD).
+//   Six kernel families are instantiated from this one template (VGPRs / scratch bytes per lane / waves per SIMD of the timed
+//   builds, csrc/_obj/resource_usage.txt): spheres only (book-one: 120 / 0 / 4, 512-thread groups, two per CU); lean general
+//   -- matrices, rectangles, cubes, node geometries -- (Cornell box, walked as a box list: 127 / 64 / 4, 256-thread groups,
+//   four per CU); general + sphere media + textures (book-two cover: 128 / 64 / 4); media over general boundaries and chains of
+//   5-15 transform levels (168 / 352 / 3); media inside the boundary of media (168 / 2160 / 3, its own compilation); and each of
+//   the general ones with 32-bit node references (> 32 767 prims or nodes).  The scratch bytes of the first three belong to
+//   real calls on paths that hardly ever run (transcendentals, the reference's boxes for rays in an axis plane: rt_lane.h).
 //
 // reduce_kernel -- pixel = (((s_0 + s_1) + s_2) + ...) / spp in sample order, the
 //   rounding of `pixel += color(...)` in examples/book-one.rs:69-76.  Per-sample

@@ -421,7 +421,7 @@ RT_HD bool medium_hit(V3 oc, V3 d, double radius, double neg_inv_density, uint64
     double t1;
     if (!sphere_t(oc, d, a, radius, &t1)) return false;
     Rec r1;
-    bool entering;
+    bool entering = false;
     bool sure = false;
     if (!RECORD) {
         r1.t = t1;

@@ -15,7 +15,7 @@
 
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define RT_LDS_HD __host__ __device__ inline
 #else
 #define RT_LDS_HD inline
@@ -28,11 +28,8 @@
 // A fourth queue in the same format -- rays whose next segment has been set up and that wait for a lane, so that lanes which finish
 // their traversal early park their hit and take one instead of idling until the wave's shade quorum -- was built and measured in
 // round 3 (profiles/r03_experiments/ray_exchange_kernel.patch): slower on every scene (cornell 2533 -> 2282,
-// cover 2121 -> 2077 Msamples/s).  The layout keeps the queue count as a parameter; the kernels use three.
-#ifndef RT_RAYQ_G
-#define RT_RAYQ_G 0
-#endif
-#define RT_RAY_QUEUE 3u    /* index of the ray queue (its state word follows the three class words in the header) */
+// cover 2121 -> 2077 Msamples/s).  The layout has the three class queues and nothing else: there is no queue count for the host and
+// the kernel to disagree about.
 #define RT_SWAP_F64 14     /* o, d, T (9), s0, s1, best_t, draws, base */
 #define RT_SWAP_F32 3      /* k, best_prim, slot */
 #define RT_SWAP_HDR_BYTES 32u
@@ -53,19 +50,16 @@ RT_LDS_HD constexpr uint32_t rt_swap_cap_effective(uint32_t block_threads, uint3
     return block_threads >= 512u ? (uint32_t)RT_SWAP_CAP : (launch_cap & ~1u);
 }
 
-// queues a kernel family keeps: the three class queues, plus the ray queue for the general families
-RT_LDS_HD constexpr uint32_t rt_swap_queues(bool general) { return (uint32_t)RT_SWAP_CLASSES + ((general && RT_RAYQ_G) ? 1u : 0u); }
-
 // node_bytes: 0 when the node array stays in global memory; swap_cap: 0 for the kernels without swap queues
 RT_LDS_HD constexpr RtLdsLayout rt_lds_layout(uint32_t stack_entries, uint32_t block_threads, uint32_t stack_entry_bytes, uint32_t node_bytes,
-                                              uint32_t swap_cap, uint32_t n_queues = RT_SWAP_CLASSES) {
+                                              uint32_t swap_cap) {
     RtLdsLayout l{};
     l.stack_off = 0u;
     l.node_off = stack_entries * block_threads * stack_entry_bytes; // multiple of 256: uint4 copies stay aligned
     l.job_off = l.node_off + ((node_bytes + 15u) & ~15u);
     l.swap_off = l.job_off + (block_threads / 64u) * RT_JOB_BYTES_PER_WAVE;
     l.swap_class_bytes = RT_SWAP_ENTRY_BYTES * swap_cap;
-    l.total = l.swap_off + (swap_cap ? RT_SWAP_HDR_BYTES + n_queues * l.swap_class_bytes : 0u);
+    l.total = l.swap_off + (swap_cap ? RT_SWAP_HDR_BYTES + (uint32_t)RT_SWAP_CLASSES * l.swap_class_bytes : 0u);
     return l;
 }
 // every region starts where its widest access needs it to
@@ -76,11 +70,11 @@ RT_LDS_HD constexpr bool rt_lds_layout_aligned(const RtLdsLayout &l) {
 // The largest EVEN capacity (<= RT_SWAP_CAP) with which `groups_per_cu` workgroups of this shape still share one CU's LDS;
 // 16 when even that does not fit (fewer groups will be resident).
 RT_LDS_HD constexpr uint32_t rt_swap_cap_that_fits(uint32_t stack_entries, uint32_t block_threads, uint32_t stack_entry_bytes, uint32_t node_bytes,
-                                                   uint32_t groups_per_cu, uint32_t n_queues = RT_SWAP_CLASSES) {
+                                                   uint32_t groups_per_cu) {
     if (block_threads >= 512u) return (uint32_t)RT_SWAP_CAP;
     const uint32_t share = (RT_LDS_PER_CU / (groups_per_cu ? groups_per_cu : 1u)) & ~(RT_LDS_GRANULE - 1u);
     const uint32_t other = rt_lds_layout(stack_entries, block_threads, stack_entry_bytes, node_bytes, 0u).total + RT_SWAP_HDR_BYTES;
-    const uint32_t per_entry = n_queues * RT_SWAP_ENTRY_BYTES;
+    const uint32_t per_entry = (uint32_t)RT_SWAP_CLASSES * RT_SWAP_ENTRY_BYTES;
     if (other + 16u * per_entry > share) return 16u;
     const uint32_t cap = (share - other) / per_entry;
     return (cap < (uint32_t)RT_SWAP_CAP ? cap : (uint32_t)RT_SWAP_CAP) & ~1u;
@@ -90,7 +84,6 @@ static_assert(rt_lds_layout_aligned(rt_lds_layout(24, 512, 4, 31 * 1024, RT_SWAP
 static_assert(rt_lds_layout_aligned(rt_lds_layout(17, 256, 4, 648, 38)), "list shape, even capacity");
 static_assert(rt_lds_layout_aligned(rt_lds_layout(13, 256, 8, 0, 16)), "wide references");
 static_assert(rt_lds_layout(10, 256, 4, 0, 0).total == 10 * 256 * 4 + 4 * RT_JOB_BYTES_PER_WAVE, "no queues: stack + job state");
-static_assert(rt_lds_layout_aligned(rt_lds_layout(15, 256, 4, 0, 50, 4)), "four queues");
 
 // device error word (RtLaunch::status): set by the kernel, turned into RT_ERR_DEVICE by the host
 #define RT_DEV_OK 0u

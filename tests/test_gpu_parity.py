@@ -725,35 +725,75 @@ def test_device_renders_in_flight_on_two_streams(rt, scenes, gpu_device):
         assert np.array_equal(im.cpu().numpy().reshape(H, W, 3), ref), (W, H, spp, seed)
 
 
+_HOOK_SCRIPT = r"""
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from __graft_entry__ import load_package
+rt = load_package()
+assert rt.version().endswith("+testhooks"), rt.version()
+scenes = importlib.import_module("ray_tracer_amd.scenes")
+dev = int(sys.argv[2])
+sc, cam = scenes.build_product(scenes.cover(1, 1.0), device=dev)
+ok = sc.render(cam, 64, 64, 4, 50, seed=1)
+os.environ["RT_TEST_LDS_SHORT"] = "1"
+try:
+    sc.render(cam, 64, 64, 4, 50, seed=1)
+    raise SystemExit("a launch with fewer LDS bytes than the layout needs was not refused")
+except rt.RtError as e:
+    assert "fewer LDS bytes" in str(e), str(e)
+del os.environ["RT_TEST_LDS_SHORT"]
+assert np.array_equal(sc.render(cam, 64, 64, 4, 50, seed=1), ok)  # the error word was cleared, the scene still renders
+# the asynchronous entry: the launch itself succeeds, rt_render_status reports
+import torch
+buf = torch.zeros(rt.shard_tile_count(64, 64, 0, 1) * 64 * 3, dtype=torch.float64, device=f"cuda:{dev}")
+os.environ["RT_TEST_LDS_SHORT"] = "1"
+sc.render_tiles_device(cam, 64, 64, 4, 50, 1, (0, 1), buf.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+try:
+    sc.status()
+    raise SystemExit("rt_render_status did not report the refused launch")
+except rt.RtError:
+    pass
+del os.environ["RT_TEST_LDS_SHORT"]
+sc.status()
+# watchdog (counting build): a bound of 3 trips cannot be met by any wave
+os.environ["RT_TEST_WATCHDOG_TRIPS"] = "3"
+try:
+    sc.render(cam, 64, 64, 4, 50, seed=1, counters=True)
+    raise SystemExit("the watchdog did not trip")
+except rt.RtError as e:
+    assert "no progress" in str(e), str(e)
+del os.environ["RT_TEST_WATCHDOG_TRIPS"]
+img, cnt = sc.render(cam, 64, 64, 4, 50, seed=1, counters=True)  # the default bound is never reached by a healthy launch
+assert np.array_equal(img, ok) and cnt["samples"] == 64 * 64 * 4
+print("HOOKS-OK")
+"""
+
+
 def test_device_error_word_instead_of_a_hang(rt, scenes, gpu_device, monkeypatch):
     """A persistent kernel has one failure mode, the hang (round 2, 05:58: the host sized the launch without a region the kernel
-    had grown).  Now (ray-tracer_amd/csrc/rt_lds.h) host and kernel share one layout function, and the kernel
+    had grown, docs/experiments.md).  Now (ray-tracer_amd/csrc/rt_lds.h) host and kernel share one layout function, and the kernel
     checks the bytes it was launched with: a short launch is refused -- RT_ERR_DEVICE, no image, no hang -- and the counting
-    build's watchdog turns a wave that makes no progress into the same error."""
+    build's watchdog turns a wave that makes no progress into the same error.  The hooks that provoke both live in
+    librt_mi355x_testhooks.so only (one more compilation of rt_api.cpp with -DRT_TEST_HOOKS, the same kernels; csrc/Makefile),
+    loaded by a child process; the shipped library reads no RT_TEST_* variable, which is asserted here as well."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    hooks = rt.LIB_PATH.with_name("librt_mi355x_testhooks.so")
+    assert hooks.exists(), f"{hooks} is missing: `make -C ray-tracer_amd/csrc` builds it beside the library"
+    env = dict(os.environ, RT_MI355X_LIB=str(hooks))
+    r = subprocess.run([sys.executable, "-c", _HOOK_SCRIPT, str(root), str(gpu_device)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "HOOKS-OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    # the shipped library: the same variables change nothing
     sc, cam = scenes.build_product(scenes.cover(1, 1.0), device=gpu_device)
     ok = sc.render(cam, 64, 64, 4, 50, seed=1)
     monkeypatch.setenv("RT_TEST_LDS_SHORT", "1")
-    with pytest.raises(rt.RtError) as e:
-        sc.render(cam, 64, 64, 4, 50, seed=1)
-    assert "fewer LDS bytes" in str(e.value)
-    monkeypatch.delenv("RT_TEST_LDS_SHORT")
-    assert np.array_equal(sc.render(cam, 64, 64, 4, 50, seed=1), ok)  # the error word was cleared, the scene still renders
-    # the asynchronous entry: the launch itself succeeds, rt_render_status reports
-    import torch
-    buf = torch.zeros(rt.shard_tile_count(64, 64, 0, 1) * 64 * 3, dtype=torch.float64, device=f"cuda:{gpu_device}")
-    monkeypatch.setenv("RT_TEST_LDS_SHORT", "1")
-    sc.render_tiles_device(cam, 64, 64, 4, 50, 1, (0, 1), buf.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
-    with pytest.raises(rt.RtError):
-        sc.status()
-    monkeypatch.delenv("RT_TEST_LDS_SHORT")
-    sc.status()
-    # watchdog (counting build): a bound of 3 trips cannot be met by any wave
     monkeypatch.setenv("RT_TEST_WATCHDOG_TRIPS", "3")
-    with pytest.raises(rt.RtError) as e:
-        sc.render(cam, 64, 64, 4, 50, seed=1, counters=True)
-    assert "no progress" in str(e.value)
-    monkeypatch.delenv("RT_TEST_WATCHDOG_TRIPS")
-    img, cnt = sc.render(cam, 64, 64, 4, 50, seed=1, counters=True)  # the default bound is never reached by a healthy launch
+    assert np.array_equal(sc.render(cam, 64, 64, 4, 50, seed=1), ok)
+    img, cnt = sc.render(cam, 64, 64, 4, 50, seed=1, counters=True)
     assert np.array_equal(img, ok) and cnt["samples"] == 64 * 64 * 4
 
 

@@ -431,11 +431,12 @@ def test_lds_layout_is_aligned_and_fits_for_every_launch_shape(lane_emul):
     node-array sizes, reference widths and kernel families the regions are ordered, aligned (node copy / job state 16 B, queues
     8 B, every class queue 8 B), the capacity is even, and `groups_per_cu` workgroups fit one CU's 160 KiB whenever the
     capacity is above the 16-entry floor."""
-    for block, groups, nq in ((512, 2, 3), (256, 4, 3), (256, 3, 3), (256, 4, 4), (256, 3, 4)):  # nq = 4: the general families' ray queue
+    nq = 3  # the three class queues: the layout has no other (rt_lds.h)
+    for block, groups in ((512, 2), (256, 4), (256, 3)):
         for entry_bytes in (4, 8):
             for stack_entries in range(1, 25):
                 for node_bytes in (0, 64, 576, 648, 1024, 9 * 64, 250 * 64, 484 * 64, 1000 * 64):
-                    l = lane_emul.lds_layout(stack_entries, block, entry_bytes, node_bytes, groups, nq)
+                    l = lane_emul.lds_layout(stack_entries, block, entry_bytes, node_bytes, groups)
                     assert l["aligned"] == 1, (block, entry_bytes, stack_entries, node_bytes, l)
                     assert l["cap"] % 2 == 0 and l["cap_effective"] % 2 == 0 and 16 <= l["cap"] <= 64
                     assert l["stack_off"] == 0 and l["node_off"] == stack_entries * block * entry_bytes
