@@ -728,6 +728,8 @@ def test_device_renders_in_flight_on_two_streams(rt, scenes, gpu_device):
 _HOOK_SCRIPT = r"""
 import importlib, os, sys
 import numpy as np
+import torch  # before the library: its own HIP runtime has to come up first in a process that uses both
+torch.cuda.init()
 sys.path.insert(0, sys.argv[1])
 from __graft_entry__ import load_package
 rt = load_package()
@@ -745,7 +747,6 @@ except rt.RtError as e:
 del os.environ["RT_TEST_LDS_SHORT"]
 assert np.array_equal(sc.render(cam, 64, 64, 4, 50, seed=1), ok)  # the error word was cleared, the scene still renders
 # the asynchronous entry: the launch itself succeeds, rt_render_status reports
-import torch
 buf = torch.zeros(rt.shard_tile_count(64, 64, 0, 1) * 64 * 3, dtype=torch.float64, device=f"cuda:{dev}")
 os.environ["RT_TEST_LDS_SHORT"] = "1"
 sc.render_tiles_device(cam, 64, 64, 4, 50, 1, (0, 1), buf.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
