@@ -447,13 +447,14 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     const unsigned groups_per_cu = std::max(1u, (unsigned)rt_kernel_waves_per_simd(feat) * 256u / block);
     const unsigned lds_share = (RT_LDS_PER_CU / groups_per_cu) & ~(RT_LDS_GRANULE - 1u);
     const int list = s->flat.n_list > 0; // the box list (< 1 KB) always lives in LDS
+    const unsigned front = rt_lds_front_bytes((feat & ~1u) != 0u); // the families with media / textures keep the log table there
     const unsigned min_cap = swap ? (block >= 512u ? (unsigned)RT_SWAP_CAP : 32u) : 0u; // the node copy must leave room for this
     const int ldsnodes = list || (!wide && node_bytes > 0 && !(no_lds && *no_lds == '1') &&
-                                  rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, node_bytes, min_cap).total <= lds_share);
+                                  rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, node_bytes, min_cap, front).total <= lds_share);
     const unsigned in_lds = ldsnodes ? node_bytes : 0u;
-    const unsigned swap_cap = swap ? rt_swap_cap_that_fits((unsigned)L.stack_entries, block, entry_bytes, in_lds, groups_per_cu) : 0u;
+    const unsigned swap_cap = swap ? rt_swap_cap_that_fits((unsigned)L.stack_entries, block, entry_bytes, in_lds, groups_per_cu, front) : 0u;
     L.swap_cap = (int)swap_cap;
-    const RtLdsLayout lay = rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, in_lds, swap ? rt_swap_cap_effective(block, swap_cap) : 0u);
+    const RtLdsLayout lay = rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, in_lds, swap ? rt_swap_cap_effective(block, swap_cap) : 0u, front);
     if (!rt_lds_layout_aligned(lay)) return fail(RT_ERR_DEVICE, "internal: misaligned LDS layout");
     const unsigned lds_bytes = lay.total;
     if (lds_bytes > RT_LDS_PER_CU) return fail(RT_ERR_UNSUPPORTED, "the scene's traversal stack does not fit a CU's LDS");

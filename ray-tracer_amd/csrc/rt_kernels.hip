@@ -211,6 +211,9 @@ __device__ __forceinline__ void store_sample(double *samples, uint32_t slot, rtl
     typedef double v2d __attribute__((ext_vector_type(2)));
     v2d *o = reinterpret_cast<v2d *>(samples + (size_t)slot * 4);
     const v2d a = {rad.x, rad.y}, b = {rad.z, 0.0};
+#if defined(RT_PROBE_NO_SAMPLE_STORE) // timing experiment only (wrong images): what the sample-record stream costs render_kernel at most
+    if (!(rad.x == -1.2345e300)) return;
+#endif
     if (RT_NT_STORE) {
         __builtin_nontemporal_store(a, o);
         __builtin_nontemporal_store(b, o + 1);
@@ -270,13 +273,14 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
     // book-one kernel 2 %)
     const uint32_t kSwapCap = SWAP ? rt_swap_cap_effective((uint32_t)kBlock, (uint32_t)L.swap_cap) : 0u;
     Stack st;
-    st.set(rt_lds);
     constexpr uint32_t kStackEntry = Stack::kEntryBytes;
     const RtNode *nodes = L.nodes;
     const uint32_t node_lds_bytes = LDSNODES ? (uint32_t)L.n_nodes * (uint32_t)sizeof(RtNode) : 0u;
     // ONE layout function for host and device (rt_lds.h); a launch that provides fewer bytes than it needs is refused
     // instead of run: every wave returns at once and the host reports RT_ERR_DEVICE
-    const RtLdsLayout lay = rt_lds_layout((uint32_t)L.stack_entries, (uint32_t)kBlock, kStackEntry, node_lds_bytes, kSwapCap);
+    const RtLdsLayout lay = rt_lds_layout((uint32_t)L.stack_entries, (uint32_t)kBlock, kStackEntry, node_lds_bytes, kSwapCap,
+                                          rt_lds_front_bytes(MEDIUM != 0 || TEXTURED));
+    st.set(rt_lds + lay.stack_off);
     const uint32_t kSwapClassBytes = lay.swap_class_bytes;
     if (lay.total > L.lds_bytes) { // wave-uniform (kernel arguments only)
         if (threadIdx.x == 0u) atomicOr(L.status, RT_DEV_ERR_LDS_LAYOUT);
@@ -291,6 +295,8 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
     unsigned char *swap_mem = rt_lds + lay.swap_off;
     uint32_t *swap_hdr = reinterpret_cast<uint32_t *>(swap_mem);
     if (SWAP && threadIdx.x < RT_SWAP_HDR_BYTES / 4u) swap_hdr[threadIdx.x] = 0u;
+    if (MEDIUM != 0 || TEXTURED) // the log table (rt_libm.h) at the front of the workgroup's LDS: rtl::log_cold reads it there
+        for (uint32_t i = threadIdx.x; i < RT_LDS_LOG_TABLE_BYTES / 8u; i += (uint32_t)kBlock) reinterpret_cast<double *>(rt_lds)[i] = rtm_log_tab[i];
     if (LDSNODES) {
         uint4 *dst = reinterpret_cast<uint4 *>(rt_lds + lay.node_off);
         const uint4 *src = reinterpret_cast<const uint4 *>(L.nodes);

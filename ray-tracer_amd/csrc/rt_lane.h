@@ -362,7 +362,16 @@ RT_COLD UV sphere_uv_cold(double qx, double qy, double qz) { // unitSphereUv, sr
     r.v = 1.0 - RTL_ACOS(qy) / RTL_PI;
     return r;
 }
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RT_TU_PART) && RT_TU_PART >= 2
+// the kernel families with media / textures (compilations 2 and 3 of rt_kernels.hip hold nothing else): glibc's log table sits at
+// the front of the workgroup's LDS (rt_lds.h RT_LDS_LOG_TABLE_BYTES, copied there at kernel entry)
+extern __shared__ __attribute__((aligned(16))) unsigned char rt_lds[];
+RT_COLD double log_cold(double x) {
+    return rtm::log_from(x, (const __attribute__((address_space(3))) double *)reinterpret_cast<const double *>(rt_lds));
+}
+#else
 RT_COLD double log_cold(double x) { return RTL_LOG(x); }
+#endif
 RT_COLD double checker_sine_cold(double u, double v) { // src/material.rs:238
     return RTL_SIN(2.0 * RTL_PI * 10.0 * u) * RTL_SIN(2.0 * RTL_PI * 10.0 * v);
 }

@@ -50,12 +50,19 @@ RT_LDS_HD constexpr uint32_t rt_swap_cap_effective(uint32_t block_threads, uint3
     return block_threads >= 512u ? (uint32_t)RT_SWAP_CAP : (launch_cap & ~1u);
 }
 
-// node_bytes: 0 when the node array stays in global memory; swap_cap: 0 for the kernels without swap queues
+// The kernel families with media keep glibc's 2 KB log table (rt_libm.h: 128 x {invc, logc}) at the very front of their LDS: a
+// free-flight draw takes its logarithm in every medium a segment crosses, and from global memory -- behind a 217 KB node array that
+// washes through the L1 -- the table's entry was an L2 access on the critical path of a call (book-two cover: +2 %).
+#define RT_LDS_LOG_TABLE_BYTES 2048u
+RT_LDS_HD constexpr uint32_t rt_lds_front_bytes(bool media_family) { return media_family ? RT_LDS_LOG_TABLE_BYTES : 0u; }
+
+// front_bytes: rt_lds_front_bytes of the family; node_bytes: 0 when the node array stays in global memory; swap_cap: 0 for the
+// kernels without swap queues
 RT_LDS_HD constexpr RtLdsLayout rt_lds_layout(uint32_t stack_entries, uint32_t block_threads, uint32_t stack_entry_bytes, uint32_t node_bytes,
-                                              uint32_t swap_cap) {
+                                              uint32_t swap_cap, uint32_t front_bytes) {
     RtLdsLayout l{};
-    l.stack_off = 0u;
-    l.node_off = stack_entries * block_threads * stack_entry_bytes; // multiple of 256: uint4 copies stay aligned
+    l.stack_off = front_bytes; // (a multiple of 256)
+    l.node_off = l.stack_off + stack_entries * block_threads * stack_entry_bytes; // multiple of 256: uint4 copies stay aligned
     l.job_off = l.node_off + ((node_bytes + 15u) & ~15u);
     l.swap_off = l.job_off + (block_threads / 64u) * RT_JOB_BYTES_PER_WAVE;
     l.swap_class_bytes = RT_SWAP_ENTRY_BYTES * swap_cap;
@@ -70,20 +77,20 @@ RT_LDS_HD constexpr bool rt_lds_layout_aligned(const RtLdsLayout &l) {
 // The largest EVEN capacity (<= RT_SWAP_CAP) with which `groups_per_cu` workgroups of this shape still share one CU's LDS;
 // 16 when even that does not fit (fewer groups will be resident).
 RT_LDS_HD constexpr uint32_t rt_swap_cap_that_fits(uint32_t stack_entries, uint32_t block_threads, uint32_t stack_entry_bytes, uint32_t node_bytes,
-                                                   uint32_t groups_per_cu) {
+                                                   uint32_t groups_per_cu, uint32_t front_bytes) {
     if (block_threads >= 512u) return (uint32_t)RT_SWAP_CAP;
     const uint32_t share = (RT_LDS_PER_CU / (groups_per_cu ? groups_per_cu : 1u)) & ~(RT_LDS_GRANULE - 1u);
-    const uint32_t other = rt_lds_layout(stack_entries, block_threads, stack_entry_bytes, node_bytes, 0u).total + RT_SWAP_HDR_BYTES;
+    const uint32_t other = rt_lds_layout(stack_entries, block_threads, stack_entry_bytes, node_bytes, 0u, front_bytes).total + RT_SWAP_HDR_BYTES;
     const uint32_t per_entry = (uint32_t)RT_SWAP_CLASSES * RT_SWAP_ENTRY_BYTES;
     if (other + 16u * per_entry > share) return 16u;
     const uint32_t cap = (share - other) / per_entry;
     return (cap < (uint32_t)RT_SWAP_CAP ? cap : (uint32_t)RT_SWAP_CAP) & ~1u;
 }
 
-static_assert(rt_lds_layout_aligned(rt_lds_layout(24, 512, 4, 31 * 1024, RT_SWAP_CAP)), "book-one shape");
-static_assert(rt_lds_layout_aligned(rt_lds_layout(17, 256, 4, 648, 38)), "list shape, even capacity");
-static_assert(rt_lds_layout_aligned(rt_lds_layout(13, 256, 8, 0, 16)), "wide references");
-static_assert(rt_lds_layout(10, 256, 4, 0, 0).total == 10 * 256 * 4 + 4 * RT_JOB_BYTES_PER_WAVE, "no queues: stack + job state");
+static_assert(rt_lds_layout_aligned(rt_lds_layout(24, 512, 4, 31 * 1024, RT_SWAP_CAP, 0)), "book-one shape");
+static_assert(rt_lds_layout_aligned(rt_lds_layout(17, 256, 4, 648, 38, RT_LDS_LOG_TABLE_BYTES)), "list shape, even capacity");
+static_assert(rt_lds_layout_aligned(rt_lds_layout(13, 256, 8, 0, 16, 0)), "wide references");
+static_assert(rt_lds_layout(10, 256, 4, 0, 0, 0).total == 10 * 256 * 4 + 4 * RT_JOB_BYTES_PER_WAVE, "no queues: stack + job state");
 
 // device error word (RtLaunch::status): set by the kernel, turned into RT_ERR_DEVICE by the host
 #define RT_DEV_OK 0u

@@ -54,7 +54,9 @@ RTM_FN double nan_() { return from_bits(0x7FF8000000000000ull); }
 // ---------------------------------------------------------------------------------------------------------------------
 // log: glibc 2.35 sysdeps/ieee754/dbl-64/e_log.c (the table-driven algorithm of ARM's optimized routines), __log_fma
 // ---------------------------------------------------------------------------------------------------------------------
-RTM_FN double log(double x) {
+// Tab: where the {invc, logc} table is read from -- rtm_log_tab, or a copy of it (the kernels with media keep one in LDS)
+template <class Tab>
+RTM_FN double log_from(double x, Tab tab) {
     const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
     const double A0 = -0x1.0000000000001p-1, A1 = 0x1.555555551305bp-2, A2 = -0x1.fffffffeb4590p-3,
                  A3 = 0x1.999b324f10111p-3, A4 = -0x1.55575e506c89fp-3;
@@ -96,7 +98,7 @@ RTM_FN double log(double x) {
     const uint32_t i = (uint32_t)(tmp >> 45) & 127u;
     const int32_t k = (int32_t)((int64_t)tmp >> 52);
     const uint64_t iz = ix - (tmp & 0xFFF0000000000000ull);
-    const double invc = rtm_log_tab[2 * i], logc = rtm_log_tab[2 * i + 1];
+    const double invc = tab[2 * i], logc = tab[2 * i + 1];
     const double z = from_bits(iz);
     const double r = fma_(z, invc, -1.0);
     const double kd = (double)k;
@@ -113,6 +115,7 @@ RTM_FN double log(double x) {
     const double y = fma_(rr2, q, lo2);
     return y + hi;
 }
+RTM_FN double log(double x) { return log_from(x, rtm_log_tab); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // sin: glibc 2.35 sysdeps/ieee754/dbl-64/s_sin.c (IBM Accurate Mathematical Library), __sin_fma

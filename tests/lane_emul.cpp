@@ -284,10 +284,10 @@ extern "C" void lane_emul_medium_forms(const double oc[3], const double d[3], do
 // the shared LDS layout (ray-tracer_amd/csrc/rt_lds.h) for host-side sweeps: out = {stack_off, node_off, job_off, swap_off,
 // swap_class_bytes, total, aligned, cap that fits, effective cap}
 extern "C" void lane_emul_lds_layout(unsigned stack_entries, unsigned block, unsigned entry_bytes, unsigned node_bytes, unsigned groups_per_cu,
-                                     unsigned *out) {
-    const uint32_t cap = rt_swap_cap_that_fits(stack_entries, block, entry_bytes, node_bytes, groups_per_cu);
+                                     unsigned front_bytes, unsigned *out) {
+    const uint32_t cap = rt_swap_cap_that_fits(stack_entries, block, entry_bytes, node_bytes, groups_per_cu, front_bytes);
     const uint32_t eff = rt_swap_cap_effective(block, cap);
-    const RtLdsLayout l = rt_lds_layout(stack_entries, block, entry_bytes, node_bytes, eff);
+    const RtLdsLayout l = rt_lds_layout(stack_entries, block, entry_bytes, node_bytes, eff, front_bytes);
     out[0] = l.stack_off;
     out[1] = l.node_off;
     out[2] = l.job_off;

@@ -61,13 +61,13 @@ def load(name):
 
 
     _LIB.lane_emul_lds_layout.restype = None
-    _LIB.lane_emul_lds_layout.argtypes = [C.c_uint] * 5 + [C.POINTER(C.c_uint)]
+    _LIB.lane_emul_lds_layout.argtypes = [C.c_uint] * 6 + [C.POINTER(C.c_uint)]
 
 
-    def lds_layout(stack_entries, block, entry_bytes, node_bytes, groups_per_cu):
+    def lds_layout(stack_entries, block, entry_bytes, node_bytes, groups_per_cu, front_bytes=0):
         """rt_lds.h for a launch shape -> dict of offsets, total, aligned, the queue capacity that fits and the one the kernel uses"""
         out = (C.c_uint * 9)()
-        _LIB.lane_emul_lds_layout(stack_entries, block, entry_bytes, node_bytes, groups_per_cu, out)
+        _LIB.lane_emul_lds_layout(stack_entries, block, entry_bytes, node_bytes, groups_per_cu, front_bytes, out)
         names = ("stack_off", "node_off", "job_off", "swap_off", "swap_class_bytes", "total", "aligned", "cap", "cap_effective")
         return dict(zip(names, [int(v) for v in out]))
 

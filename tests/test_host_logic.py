@@ -432,14 +432,14 @@ def test_lds_layout_is_aligned_and_fits_for_every_launch_shape(lane_emul):
     8 B, every class queue 8 B), the capacity is even, and `groups_per_cu` workgroups fit one CU's 160 KiB whenever the
     capacity is above the 16-entry floor."""
     nq = 3  # the three class queues: the layout has no other (rt_lds.h)
-    for block, groups in ((512, 2), (256, 4), (256, 3)):
+    for block, groups, front in ((512, 2, 0), (256, 4, 0), (256, 3, 0), (256, 4, 2048), (256, 3, 2048)):  # front: the log table of the media families
         for entry_bytes in (4, 8):
             for stack_entries in range(1, 25):
                 for node_bytes in (0, 64, 576, 648, 1024, 9 * 64, 250 * 64, 484 * 64, 1000 * 64):
-                    l = lane_emul.lds_layout(stack_entries, block, entry_bytes, node_bytes, groups)
+                    l = lane_emul.lds_layout(stack_entries, block, entry_bytes, node_bytes, groups, front)
                     assert l["aligned"] == 1, (block, entry_bytes, stack_entries, node_bytes, l)
                     assert l["cap"] % 2 == 0 and l["cap_effective"] % 2 == 0 and 16 <= l["cap"] <= 64
-                    assert l["stack_off"] == 0 and l["node_off"] == stack_entries * block * entry_bytes
+                    assert l["stack_off"] == front and l["node_off"] == front + stack_entries * block * entry_bytes
                     assert l["job_off"] >= l["node_off"] + node_bytes and l["swap_off"] == l["job_off"] + (block // 64) * 32
                     for cls in range(nq):  # every queue starts 8-byte aligned (its first 14 arrays are binary64)
                         assert (l["swap_off"] + 32 + cls * l["swap_class_bytes"]) % 8 == 0
