@@ -26,6 +26,7 @@ struct Call {
 };
 static std::vector<Call> *sink = nullptr;
 static std::vector<double> *seg_sink = nullptr; // lane_emul_trace_segments: {sample, o, d, t, prim} per segment
+static bool seg_wide = false;                   // lane_emul_dump_segments: + {stream key bits, segment number}
 static int cur_sample = 0;
 static inline double rec(int fn, double a, double b, double r) {
     if (sink) sink->push_back(Call{cur_sample, fn, a, b, r});
@@ -152,6 +153,12 @@ void run(const RtLaunch &L, int x0, int y0, int x1, int y1, double *out, double 
                     if (lane_trace::seg_sink) {
                         const double row[9] = {(double)s, ps.o.x, ps.o.y, ps.o.z, ps.d.x, ps.d.y, ps.d.z, tv.best_t, (double)tv.best_prim};
                         lane_trace::seg_sink->insert(lane_trace::seg_sink->end(), row, row + 9);
+                        if (lane_trace::seg_wide) { // + the stream key (raw bits) and the segment number: what a keyed medium draw needs
+                            double key;
+                            std::memcpy(&key, &ps.g.base, sizeof key);
+                            const double more[2] = {key, (double)ps.k};
+                            lane_trace::seg_sink->insert(lane_trace::seg_sink->end(), more, more + 2);
+                        }
                     }
                     if (rtl::finish_segment<G, M, T>(L, &ps, tv, &rad)) break;
                 }
@@ -391,6 +398,25 @@ extern "C" long lane_emul_trace_segments(rt_scene *s, const rt_camera *cam, int 
     if (rc != 0) return -1;
     const long n = (long)(rows.size() / 9);
     for (long i = 0; i < n && i < max_rows; ++i) std::memcpy(out + 9 * i, rows.data() + 9 * (size_t)i, 9 * sizeof(double));
+    return n;
+}
+
+// Every segment of a REGION's samples: rows of 11 doubles {sample, o[3], d[3], t, prim, stream key (raw 64 bits), segment number};
+// returns the number of rows (may exceed max_rows: then only the first are stored).  tools/wavefront_probe.py
+extern "C" long lane_emul_dump_segments(rt_scene *s, const rt_camera *cam, int W, int H, int spp, int max_depth, uint64_t seed, int x0, int y0, int x1,
+                                        int y1, double *out, long max_rows) {
+    std::vector<double> rows;
+    std::vector<double> img((size_t)W * (size_t)H * 3);
+    unsigned long long cnt[5];
+    int hw = 0;
+    lane_trace::seg_sink = &rows;
+    lane_trace::seg_wide = true;
+    const int rc = lane_emul_render(s, cam, W, H, spp, max_depth, seed, x0, y0, x1, y1, img.data(), nullptr, -1, -1, cnt, &hw);
+    lane_trace::seg_sink = nullptr;
+    lane_trace::seg_wide = false;
+    if (rc != 0) return -1;
+    const long n = (long)(rows.size() / 11);
+    for (long i = 0; i < n && i < max_rows; ++i) std::memcpy(out + 11 * i, rows.data() + 11 * (size_t)i, 11 * sizeof(double));
     return n;
 }
 

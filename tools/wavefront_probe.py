@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""GPU box, one-off: the traversal-side stages of a WAVEFRONT organisation of the book-two cover scene, measured.
+ray-tracer_amd/csrc/rt_probe.hip (make -C ray-tracer_amd/csrc probe) holds the two kernels; the segments they work on are the real
+segments of the scene's paths, recorded by the CPU lane program (16 processes).  -> gpurun_out/wavefront_probe.json"""
+import ctypes as C
+import importlib
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+W = H = int(os.environ.get("PROBE_EDGE", "400"))
+SPP = int(os.environ.get("PROBE_SPP", "6"))
+DEPTH, SEED = 100, 1
+
+
+def record(band):
+    """the segments of rows [y0, y1) as the lane program walks them"""
+    from __graft_entry__ import load_package
+    load_package()
+    scenes = importlib.import_module("ray_tracer_amd.scenes")
+    lib = C.CDLL(str(ROOT / "tests" / "_build" / "liblane_emul.so"))
+    lib.lane_emul_dump_segments.restype = C.c_long
+    lib.lane_emul_dump_segments.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_uint64] + [C.c_int] * 4 + [C.POINTER(C.c_double), C.c_long]
+    sc, cam = scenes.build_product(scenes.cover(1, 1.0), device=-1)
+    y0, y1 = band
+    cap = (y1 - y0) * W * SPP * 8
+    out = np.zeros((cap, 11))
+    n = lib.lane_emul_dump_segments(sc._h, C.addressof(cam.c), W, H, SPP, DEPTH, SEED, 0, y0, W, y1, out.ctypes.data_as(C.POINTER(C.c_double)), cap)
+    assert 0 <= n <= cap, (n, cap)
+    return out[:n].copy()
+
+
+def main():
+    os.environ["RT_MI355X_LIB"] = str(ROOT / "ray-tracer_amd" / "lib" / "librt_mi355x_travprobe.so")
+    t0 = time.time()
+    procs = 16
+    bands = [(H * i // procs, H * (i + 1) // procs) for i in range(procs)]
+    with mp.get_context("spawn").Pool(procs) as pool:
+        rows = np.concatenate(pool.map(record, bands))
+    n = len(rows)
+    print(f"recorded {n} segments of {W * H * SPP} samples in {time.time() - t0:.1f} s", flush=True)
+    # shuffle the paths' order as a pool of a wavefront tracer would see them: rays of all depths mixed, neighbours apart
+    rng = np.random.default_rng(1)
+    order_mixed = rng.permutation(n)
+    rays = np.zeros(n, dtype=[("o", "f8", 3), ("d", "f8", 3), ("base", "u8"), ("k", "u4"), ("pad", "u4")])
+    rays["o"], rays["d"] = rows[:, 1:4], rows[:, 4:7]
+    rays["base"] = rows[:, 9].copy().view(np.uint64)
+    rays["k"] = rows[:, 10].astype(np.uint32)
+    want_t, want_prim = rows[:, 7], rows[:, 8]
+
+    from __graft_entry__ import load_package
+    rt = load_package()
+    scenes = importlib.import_module("ray_tracer_amd.scenes")
+    sc, cam = scenes.build_product(scenes.cover(1, 1.0), device=0)
+    lib = C.CDLL(os.environ["RT_MI355X_LIB"])
+    lib.rt_probe_traverse.restype = C.c_int
+    lib.rt_probe_traverse.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_ulonglong)]
+    # the megakernel on the same image, for the same number of segments
+    sc.render(cam, W, H, SPP, DEPTH, SEED)
+    _, cnt = sc.render(cam, W, H, SPP, DEPTH, SEED, counters=True)
+    assert cnt["segments"] == n, (cnt["segments"], n)
+    res = {"scene": "book-two cover", "image": [W, H, SPP], "segments": n, "megakernel_counters": {k: int(v) for k, v in cnt.items()}, "runs": []}
+    hits = np.zeros(n, dtype=[("t", "f8"), ("prim", "u4"), ("pad", "u4")])
+    for name, order in (("path order (pixel-major, a path's segments adjacent)", np.arange(n)), ("mixed (random order)", order_mixed)):
+        r = np.ascontiguousarray(rays[order])
+        for fetch_min, vote_leaf, node_keep in ((1, 16, 8), (8, 16, 8), (16, 16, 8), (32, 16, 8), (16, 8, 8), (16, 32, 8), (16, 16, 16)):
+            ms = (C.c_double * 3)()
+            stats = (C.c_ulonglong * 6)()
+            rc = lib.rt_probe_traverse(sc._h, r.ctypes.data, n, fetch_min, vote_leaf, node_keep, 3, ms, hits.ctypes.data, stats)
+            assert rc == 0, rc
+            ok = np.array_equal(hits["t"], want_t[order]) and np.array_equal(hits["prim"].astype(np.float64), np.where(want_prim[order] > 4e9, 4294967295.0, want_prim[order]))
+            st = [int(v) for v in stats]
+            run = {"order": name, "fetch_min": fetch_min, "vote_leaf": vote_leaf, "node_keep": node_keep, "begin_ms": ms[0], "traverse_ms": ms[1], "blocks": int(ms[2]),
+                   "results_equal_the_lane_program": bool(ok), "ns_per_segment": {"begin": ms[0] * 1e6 / n, "traverse": ms[1] * 1e6 / n},
+                   "node_block_occupancy": st[1] / max(1, 64 * st[0]), "leaf_block_occupancy": st[3] / max(1, 64 * st[2]),
+                   "fetch_occupancy": st[5] / max(1, 64 * st[4]), "block_executions": {"node": st[0], "leaf": st[2], "fetch": st[4]}}
+            print(run, flush=True)
+            res["runs"].append(run)
+    # the whole-render figures these stand against: 800 x 800 x 1000 spp = 2.25 G segments in ~302 ms
+    (ROOT / "gpurun_out").mkdir(exist_ok=True)
+    json.dump(res, open(ROOT / "gpurun_out" / "wavefront_probe.json", "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
