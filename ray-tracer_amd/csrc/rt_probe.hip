@@ -13,6 +13,7 @@
 #define RT_TU_PART 4
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -63,11 +64,14 @@ __device__ __forceinline__ void log_table_to_lds() { // rt_lds.h RT_LDS_LOG_TABL
 }
 
 // stage 1: begin every segment (general + sphere media + textures family: <true, 1>)
-__global__ __launch_bounds__(kBlock, 4) void begin_kernel(const RtLaunch L, const ProbeRay *rays, uint32_t n, ProbeBegun *out) {
+// (`total` >= n: the recorded rays are gone through again and again, ray j = rays[j % n], until the launch is long enough for a
+// steady-state figure -- a few rays per lane measure the launch's start and tail, not the stage)
+__global__ __launch_bounds__(kBlock, 4) void begin_kernel(const RtLaunch L, const ProbeRay *rays, uint32_t n, uint32_t total, ProbeBegun *out) {
     log_table_to_lds();
     LdsStack16 st;
     st.set(rt_lds + RT_LDS_LOG_TABLE_BYTES);
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < total; j += gridDim.x * kBlock) {
+        const uint32_t i = j % n;
         const ProbeRay r = rays[i];
         rtl::PathState ps;
         ps.o = rtl::mk(r.o[0], r.o[1], r.o[2]);
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(kBlock, 4) void begin_kernel(const RtLaunch L, cons
 // stage 2: persistent traversal with immediate refill from the global ray queue
 // stats (per launch, lane 0 of each wave): [0] node-block executions, [1] lanes at a node in them, [2] leaf-block executions,
 // [3] lanes at a leaf, [4] fetch executions, [5] lanes fetched
-__global__ __launch_bounds__(kBlock, 4) void traverse_kernel(const RtLaunch L, const ProbeRay *rays, const ProbeBegun *begun, uint32_t n,
+__global__ __launch_bounds__(kBlock, 4) void traverse_kernel(const RtLaunch L, const ProbeRay *rays, const ProbeBegun *begun, uint32_t n, uint32_t total,
                                                              unsigned int *counter, ProbeHit *out, int fetch_min, int vote_leaf, int node_keep,
                                                              unsigned long long *stats) {
     typedef RtRef16 Ref;
@@ -103,6 +107,8 @@ __global__ __launch_bounds__(kBlock, 4) void traverse_kernel(const RtLaunch L, c
     tv.best_prim = 0xFFFFFFFFu;
     tv.best_t = 0.0;
     uint32_t idx = 0;
+    uint32_t chunk_next = 0, chunk_end = 0; // wave-uniform
+    constexpr int kChunk = 4096;
     bool has = false, drained = false;
     unsigned long long s_nw = 0, s_nl = 0, s_lw = 0, s_ll = 0, s_fw = 0, s_fl = 0, prims = 0;
     const bool lane0 = (threadIdx.x & 63u) == 0u;
@@ -123,20 +129,31 @@ __global__ __launch_bounds__(kBlock, 4) void traverse_kernel(const RtLaunch L, c
                 out[idx] = h;
                 has = false;
             }
+            // ray indices come in chunks of kChunk per wave (one global atomic per chunk, like the megakernel's jobs: one atomic per
+            // fetch on a single counter was what the first form of this probe measured -- its time went with the number of fetches)
             const unsigned long long m = __ballot(!has && !drained);
             const uint32_t want = (uint32_t)__popcll(m);
             uint32_t first = 0;
             if (want != 0u) {
-                const int leader = __ffsll((long long)m) - 1;
-                if ((int)(threadIdx.x & 63u) == leader) first = atomicAdd(counter, want);
-                first = (uint32_t)__builtin_amdgcn_readlane((int)first, leader);
+                if (chunk_next + want > chunk_end) { // (wave-uniform) the rest of the old chunk is dropped into the next one's count
+                    uint32_t c = 0;
+                    const int leader = __ffsll((long long)m) - 1;
+                    if ((int)(threadIdx.x & 63u) == leader) c = atomicAdd(counter, (unsigned)kChunk);
+                    c = (uint32_t)__builtin_amdgcn_readlane((int)c, leader);
+                    // the unused tail of the previous chunk: those rays are simply not traversed by anybody (the figure is per ray
+                    // actually traversed; `done_rays` counts them)
+                    chunk_next = c;
+                    chunk_end = c + (uint32_t)kChunk;
+                }
+                first = chunk_next;
+                chunk_next += want;
             }
             if (!has && !drained) {
                 const uint32_t mine = first + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63u)) - 1ull));
-                if (mine < n) {
-                    idx = mine;
-                    const ProbeRay r = rays[mine];
-                    const ProbeBegun b = begun[mine];
+                if (mine < total) {
+                    idx = mine % n;
+                    const ProbeRay r = rays[idx];
+                    const ProbeBegun b = begun[idx];
                     ps.o = rtl::mk(r.o[0], r.o[1], r.o[2]);
                     ps.d = rtl::mk(r.d[0], r.d[1], r.d[2]);
                     ps.k = (int32_t)r.k;
@@ -159,6 +176,7 @@ __global__ __launch_bounds__(kBlock, 4) void traverse_kernel(const RtLaunch L, c
                 ++s_fw;
                 s_fl += want;
             }
+            (void)first;
         } else if (nL >= vote_leaf || nN == 0) {
             if (is_leaf) rtl::leaf_step<true, 1, true>(L, &ps, tv, st, &prims);
             if (lane0) {
@@ -202,9 +220,10 @@ __global__ __launch_bounds__(kBlock, 4) void traverse_kernel(const RtLaunch L, c
 // rays: n records of 80 bytes {o[3], d[3], base, k, pad}; hits_out: n x {t, prim, pad}; ms_out: {begin_kernel, traverse_kernel} (best of
 // `repeats`); stats_out: 6 counters of the last traverse launch.  The scene must be committed on a device with a tree (no list mode)
 // and belong to the general + sphere media family.
-extern "C" int rt_probe_traverse(rt_scene *s, const void *rays_host, int n, int fetch_min, int vote_leaf, int node_keep, int repeats, double *ms_out,
+extern "C" int rt_probe_traverse(rt_scene *s, const void *rays_host, int n, int replicate, int fetch_min, int vote_leaf, int node_keep, int repeats, double *ms_out,
                                  void *hits_out, unsigned long long *stats_out) {
-    if (!s || !s->committed || s->device < 0 || n <= 0) return -1;
+    if (!s || !s->committed || s->device < 0 || n <= 0 || replicate < 1 || (long long)n * replicate > 0xFFFFFFF0ll) return -1;
+    const uint32_t total = (uint32_t)n * (uint32_t)replicate;
     if (s->flat.n_list != 0 || s->flat.wide) return -2;
     PROBE_TRY(hipSetDevice(s->device));
     RtLaunch L;
@@ -251,7 +270,7 @@ extern "C" int rt_probe_traverse(rt_scene *s, const void *rays_host, int n, int 
     double best_b = 1e30, best_t = 1e30;
     for (int rep = 0; rep < repeats; ++rep) {
         PROBE_TRY(hipEventRecord(e0, nullptr));
-        hipLaunchKernelGGL(begin_kernel, dim3((unsigned)std::min(blocks * 4, (n + kBlock - 1) / kBlock)), dim3(kBlock), lds, nullptr, L, d_rays, (uint32_t)n, d_begun);
+        hipLaunchKernelGGL(begin_kernel, dim3((unsigned)std::min(blocks * 4, (n + kBlock - 1) / kBlock)), dim3(kBlock), lds, nullptr, L, d_rays, (uint32_t)n, total, d_begun);
         PROBE_TRY(hipEventRecord(e1, nullptr));
         PROBE_TRY(hipEventSynchronize(e1));
         float ms = 0.0f;
@@ -260,7 +279,7 @@ extern "C" int rt_probe_traverse(rt_scene *s, const void *rays_host, int n, int 
         PROBE_TRY(hipMemset(d_counter, 0, 256));
         PROBE_TRY(hipMemset(d_stats, 0, 64));
         PROBE_TRY(hipEventRecord(e0, nullptr));
-        hipLaunchKernelGGL(traverse_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, nullptr, L, d_rays, d_begun, (uint32_t)n, d_counter, d_hits, fetch_min,
+        hipLaunchKernelGGL(traverse_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, nullptr, L, d_rays, d_begun, (uint32_t)n, total, d_counter, d_hits, fetch_min,
                            vote_leaf, node_keep, d_stats);
         PROBE_TRY(hipEventRecord(e1, nullptr));
         PROBE_TRY(hipEventSynchronize(e1));

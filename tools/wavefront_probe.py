@@ -16,6 +16,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
+REP = int(os.environ.get("PROBE_REPLICATE", "16"))  # the recorded segments are gone through this many times per launch (steady state)
 W = H = int(os.environ.get("PROBE_EDGE", "400"))
 SPP = int(os.environ.get("PROBE_SPP", "6"))
 DEPTH, SEED = 100, 1
@@ -62,24 +63,39 @@ def main():
     sc, cam = scenes.build_product(scenes.cover(1, 1.0), device=0)
     lib = C.CDLL(os.environ["RT_MI355X_LIB"])
     lib.rt_probe_traverse.restype = C.c_int
-    lib.rt_probe_traverse.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_ulonglong)]
+    lib.rt_probe_traverse.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_ulonglong)]
     # the megakernel on the same image, for the same number of segments
-    sc.render(cam, W, H, SPP, DEPTH, SEED)
+    mk = []
+    for _ in range(3):
+        sc.render(cam, W, H, SPP, DEPTH, SEED)
+        mk.append(sc.last_kernel_ms())
     _, cnt = sc.render(cam, W, H, SPP, DEPTH, SEED, counters=True)
     assert cnt["segments"] == n, (cnt["segments"], n)
-    res = {"scene": "book-two cover", "image": [W, H, SPP], "segments": n, "megakernel_counters": {k: int(v) for k, v in cnt.items()}, "runs": []}
+    full = {}  # the megakernel's steady state: the BASELINE config itself, 800 x 800 x 1000 spp
+    if os.environ.get("PROBE_FULL", "1") == "1":
+        sc.render(cam, 800, 800, 1000, DEPTH, SEED)
+        full_ms = sc.last_kernel_ms()
+        _, c16 = sc.render(cam, 800, 800, 16, DEPTH, SEED, counters=True)
+        seg_per_sample = c16["segments"] / c16["samples"]
+        full = {"render_kernel_ms_800x800x1000": full_ms, "segments_per_sample": seg_per_sample,
+                "ns_per_segment": full_ms * 1e6 / (800 * 800 * 1000 * seg_per_sample)}
+        print("megakernel, whole config:", full, flush=True)
+    res = {"scene": "book-two cover", "image": [W, H, SPP], "segments": n, "megakernel_steady_state": full, "megakernel_counters": {k: int(v) for k, v in cnt.items()},
+           "megakernel_render_kernel_ms_same_image": min(mk), "megakernel_ns_per_segment": min(mk) * 1e6 / n, "runs": []}
+    print("megakernel on this image:", min(mk), "ms =", min(mk) * 1e6 / n, "ns per segment", flush=True)
     hits = np.zeros(n, dtype=[("t", "f8"), ("prim", "u4"), ("pad", "u4")])
     for name, order in (("path order (pixel-major, a path's segments adjacent)", np.arange(n)), ("mixed (random order)", order_mixed)):
         r = np.ascontiguousarray(rays[order])
-        for fetch_min, vote_leaf, node_keep in ((1, 16, 8), (8, 16, 8), (16, 16, 8), (32, 16, 8), (16, 8, 8), (16, 32, 8), (16, 16, 16)):
+        for fetch_min, vote_leaf, node_keep in ((8, 16, 8), (16, 16, 8), (32, 16, 8), (48, 16, 8), (32, 32, 8), (32, 16, 16)):
             ms = (C.c_double * 3)()
             stats = (C.c_ulonglong * 6)()
-            rc = lib.rt_probe_traverse(sc._h, r.ctypes.data, n, fetch_min, vote_leaf, node_keep, 3, ms, hits.ctypes.data, stats)
+            rc = lib.rt_probe_traverse(sc._h, r.ctypes.data, n, REP, fetch_min, vote_leaf, node_keep, 2, ms, hits.ctypes.data, stats)
             assert rc == 0, rc
             ok = np.array_equal(hits["t"], want_t[order]) and np.array_equal(hits["prim"].astype(np.float64), np.where(want_prim[order] > 4e9, 4294967295.0, want_prim[order]))
             st = [int(v) for v in stats]
             run = {"order": name, "fetch_min": fetch_min, "vote_leaf": vote_leaf, "node_keep": node_keep, "begin_ms": ms[0], "traverse_ms": ms[1], "blocks": int(ms[2]),
-                   "results_equal_the_lane_program": bool(ok), "ns_per_segment": {"begin": ms[0] * 1e6 / n, "traverse": ms[1] * 1e6 / n},
+                   "replicate": REP, "results_equal_the_lane_program": bool(ok), "ns_per_segment": {"begin": ms[0] * 1e6 / (n * REP), "traverse": ms[1] * 1e6 / max(1, min(int(stats[5]), n * REP))},
+                   "rays_traversed": min(int(stats[5]), n * REP),
                    "node_block_occupancy": st[1] / max(1, 64 * st[0]), "leaf_block_occupancy": st[3] / max(1, 64 * st[2]),
                    "fetch_occupancy": st[5] / max(1, 64 * st[4]), "block_executions": {"node": st[0], "leaf": st[2], "fetch": st[4]}}
             print(run, flush=True)
