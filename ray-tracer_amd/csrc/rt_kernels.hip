@@ -469,9 +469,12 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                 unsigned char *qbase = swap_mem + RT_SWAP_HDR_BYTES;
                 // 4. park the lanes of the other classes (every class in "new" mode)
                 if (cls < (uint32_t)RT_SWAP_CLASSES && allow_push && (mode_new || cls != cstar)) {
-                    const unsigned long long mc = cls == 0u ? m0 : (cls == 1u ? m1 : m2);
-                    const uint32_t g = cls == 0u ? g0 : (cls == 1u ? g1 : g2), c = cls == 0u ? k0 : (cls == 1u ? k1 : k2);
-                    const uint32_t idx = c + lane_rank(mc);
+                    // the lane's place in its class's queue: count + rank among the class's lanes.  The three masks and counts are
+                    // wave-uniform (SGPRs): rank each against its own mask (v_mbcnt with scalar operands) and select the sums, instead
+                    // of selecting a per-lane 64-bit mask first (VERDICT r3 #5 i)
+                    const uint32_t i0 = k0 + lane_rank(m0), i1 = k1 + lane_rank(m1), i2 = k2 + lane_rank(m2);
+                    const uint32_t g = cls == 0u ? g0 : (cls == 1u ? g1 : g2);
+                    const uint32_t idx = cls == 0u ? i0 : (cls == 1u ? i1 : i2);
                     if (g != 0u && idx < kSwapCap) {
                         double *f64 = reinterpret_cast<double *>(qbase + cls * kSwapClassBytes) + idx;
                         uint32_t *f32 = reinterpret_cast<uint32_t *>(qbase + cls * kSwapClassBytes + RT_SWAP_F64 * 8 * kSwapCap) + idx;
