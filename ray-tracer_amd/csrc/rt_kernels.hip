@@ -86,14 +86,14 @@
 #define RT_VOTE_SHADE_G 48
 #endif
 #ifndef RT_VOTE_LEAF_G
-#define RT_VOTE_LEAF_G 16
+#define RT_VOTE_LEAF_G 12 /* round 4 sweep with RT_NODE_KEEP_G (profiles/r04_experiments/ab_votes*.log): cover 300.9 -> 294.7 ms at 12 / 12 */
 #endif
 // the lean general family (no media / textures: the Cornell box): shade block 42 % of the time, quorum sweep 32..64 -> 56
 #ifndef RT_VOTE_SHADE_LEAN
 #define RT_VOTE_SHADE_LEAN 56
 #endif
 #ifndef RT_NODE_KEEP_G
-#define RT_NODE_KEEP_G 8
+#define RT_NODE_KEEP_G 12 /* (8 until round 4; 16 / 12: 295.4, 16 / 16: 298.7, 24 / 16: 301.4, 32 / 16: 306.1, 8 / 24: 310.6) */
 #endif
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 4 /* spheres-only kernel: 105 VGPRs fit 4 waves per SIMD */
