@@ -73,7 +73,8 @@
 // vote thresholds (lanes).  A block runs when at least this many lanes wait for
 // it, or when no cheaper block has work.
 #ifndef RT_VOTE_SHADE
-#define RT_VOTE_SHADE 48
+#define RT_VOTE_SHADE 56 /* (48 until round 4) book-one kernel: 40: 65.3 ms, 48: 63.5, 52: 63.4, 56: 62.95, 58: 63.5, 60: 64.0, 64: 68.2
+                            (profiles/r04_experiments/ab_votes_book*.log; node-keep 12 / 16 and leaf vote 12 / 24: nothing) */
 #endif
 #ifndef RT_VOTE_LEAF
 #define RT_VOTE_LEAF 16
