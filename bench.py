@@ -21,7 +21,7 @@ The JSON line carries
   roofline      what bounds render_kernel: VALU issue.  The scene (< 1 MB) lives in LDS / L1 / L2, so HBM is not the
                 roof (0.27 TB/s of real traffic = 3 % of peak; the algorithmic bytes of SURVEY.md 8(d) are kept as the
                 secondary "hbm_equivalent" object).  achieved = sum over instruction classes of (wave instructions per
-                launch, rocprofv3 SQ_INSTS_VALU_* of profiles/r03_<scene>/summary.json) x (issue cycles per instruction
+                launch, rocprofv3 SQ_INSTS_VALU_* of profiles/rNN_<scene>/summary.json) x (issue cycles per instruction
                 per SIMD measured on the MI355X, profiles/r02_valu_issue.json) / (kernel duration measured live here
                 with HIP events); peak = 1024 SIMDs x 2.4 GHz.  Beside frac: its envelope with the unclassified half of the
                 instructions at 2 and at 4 cycles, f64_math_frac (binary64 arithmetic alone) and valu_busy_frac_pmc (the
@@ -122,8 +122,9 @@ def issue_roofline(rt, scene, W, H, spp, depth, world, kernel_ms, lane_util):
     """VALU-issue roofline of render_kernel from the committed rocprofv3 summary of this workload, if it belongs to this build."""
     out = {"bound": "valu_issue", "achieved": None, "peak": N_SIMD * MAX_CLOCK_GHZ, "unit": "Gcycle/s (VALU issue cycles, all 1024 SIMDs)",
            "frac": None, "useful_frac": None, "traffic": None, "source": None}
-    prof = next((p for p in (ROOT / "profiles" / f"r03_{scene}" / "summary.json", ROOT / "profiles" / f"r02_{scene}" / "summary.json") if p.exists()),
-                ROOT / "profiles" / f"r03_{scene}" / "summary.json")
+    # the newest committed profile of this scene (profiles/rNN_<scene>/summary.json)
+    cands = sorted((ROOT / "profiles").glob(f"r[0-9][0-9]_{scene}/summary.json"), reverse=True)
+    prof = cands[0] if cands else ROOT / "profiles" / f"r04_{scene}" / "summary.json"
     if world != 1:
         out["reason"] = "instruction counts are profiled on the whole image (N = 1) only"
         return out
