@@ -299,7 +299,9 @@ int rt_scene_prim_bounds(const rt_scene *, int prim, double out[6]);
 int rt_probe_device_math(int device, const double *a, const double *b, int n, double *out_sqrt_a, double *out_a_div_b);
 /* ... and the kernels' transcendentals -- the host libm's functions restated for the device (csrc/rt_libm.h), standing
  * for `f64::ln` (src/volume.rs:59-60,81-82), `sin` (src/material.rs:238), `acos` and `atan2` (src/geometry.rs:35-39):
- * which = 0 log(a), 1 sin(a), 2 acos(a), 3 atan2(a, b); the GPU tests compare the results with glibc's bit for bit */
+ * which = 0 log(a), 1 sin(a), 2 acos(a), 3 atan2(a, b); the GPU tests compare the results with glibc's bit for bit.
+ * Also 4 cos(a), 5 pow(a, b): restated and pinned the same way (`f64::cos`, `powf`: src/material.rs:140-143), not called by the
+ * kernels (csrc/rt_lane.h schlick_reflects says why) */
 int rt_probe_device_libm(int device, int which, const double *a, const double *b, int n, double *out);
 
 #define RT_FEAT_SPHERE_T 1u   /* translation-only sphere sprites */

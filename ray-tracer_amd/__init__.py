@@ -483,11 +483,11 @@ def device_count() -> int:
     return int(lib().rt_device_count())
 
 
-LIBM_FUNCTIONS = ("log", "sin", "acos", "atan2")
+LIBM_FUNCTIONS = ("log", "sin", "acos", "atan2", "cos", "pow")
 
 
 def probe_device_libm(which: str, a: np.ndarray, b: np.ndarray = None, device=0) -> np.ndarray:
-    """the kernels' log / sin / acos / atan2 (a, b) on the device (csrc/rt_libm.h)"""
+    """the restated host libm on the device (csrc/rt_libm.h): log / sin / acos / atan2 (a, b) -- what the kernels call -- and cos / pow (a, b)"""
     a = np.ascontiguousarray(a, dtype=np.float64)
     b = np.ascontiguousarray(a if b is None else b, dtype=np.float64)
     out = np.zeros_like(a)

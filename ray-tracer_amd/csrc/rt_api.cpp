@@ -1017,7 +1017,7 @@ int rt_probe_device_math(int device, const double *a, const double *b, int n, do
 }
 
 int rt_probe_device_libm(int device, int which, const double *a, const double *b, int n, double *out) {
-    if (!a || !b || !out || n <= 0 || which < 0 || which > 3) return fail(RT_ERR_INVALID, "bad argument");
+    if (!a || !b || !out || n <= 0 || which < 0 || which > 5) return fail(RT_ERR_INVALID, "bad argument");
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || device < 0 || device >= cnt) return fail(RT_ERR_DEVICE, "no such HIP device");
     HIP_TRY(hipSetDevice(device));

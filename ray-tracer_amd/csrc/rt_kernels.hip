@@ -863,6 +863,8 @@ __global__ void probe_libm_kernel(int which, const double *a, const double *b, i
     case 0: r = rtm::log(a[i]); break;
     case 1: r = rtm::sin(a[i]); break;
     case 2: r = rtm::acos(a[i]); break;
+    case 4: r = rtm::cos(a[i]); break;
+    case 5: r = rtm::pow(a[i], b[i]); break;
     default: r = rtm::atan2(a[i], b[i]); break;
     }
     out[i] = r;

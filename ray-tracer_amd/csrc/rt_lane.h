@@ -1137,10 +1137,14 @@ RT_HD V3 texture_value(const RtLaunch &L, uint32_t tex, double u, double v) {
 }
 
 // Dielectric::schlickReflectionProbability(theta = acos(c), n1, n2) (src/material.rs:140-143)
-// evaluated from c directly: powf(2) -> q*q, cos(acos(c)) -> c, powf(5) by multiplication.
-// Each substitution moves the probability by a few ulp at most (the reference's own libm
-// calls are only faithful to that level, and the value is only ever compared with a
-// uniform draw).  acos(c) is NaN for |c| > 1, which makes the reference refract: kept.
+// evaluated from c directly: powf(2) -> q*q, cos(acos(c)) -> c, powf(5) by multiplication.  Each substitution moves the
+// probability by a few ulp at most, and the value is only ever compared with a uniform draw: in 200 M random (c, index, draw)
+// triples the decision never differs from the reference's own evaluation with the host libm's acos / cos / pow
+// (tests/test_libm_cpu.py::test_schlick_by_multiplication_decides_like_the_reference); deviation (ii) of docs/parity.md.
+// (The reference's evaluation, restated bit for bit, exists -- rtm::acos / cos / pow -- and a draw within 1e-9 of the threshold
+// could be handed to it.  Tried in round 4: as a real call its 54 VGPRs push the spheres-only kernel from 120 to 128, inline its
+// constants are hoisted into the persistent loop; either costs the headline 1 % for a decision that changes once in 1e15 draws.)
+// acos(c) is NaN for |c| > 1, which makes the reference refract: kept.
 RT_HD bool schlick_reflects(double c, double n1, double n2, double u) {
     if (!(c >= -1.0 && c <= 1.0)) return false; // u < NaN
     double q = (n1 - n2) / (n1 + n2);

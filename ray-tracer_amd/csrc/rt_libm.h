@@ -1,4 +1,4 @@
-// rt_libm.h -- binary64 log / sin / acos / atan2 that return the bits of the HOST's libm.
+// rt_libm.h -- binary64 log / sin / cos / acos / atan2 / pow that return the bits of the HOST's libm.
 //
 // The reference takes its transcendentals from the platform libm (`f64::ln`, `sin`, `acos`, `atan2`:
 // src/volume.rs:59-60,81-82, src/geometry.rs:35-39, src/material.rs:238) -- on the machines this library runs beside,
@@ -279,6 +279,26 @@ RTM_FN double sin(double x) {
     return nan_(); // infinite or NaN
 }
 
+// cos: the same file (__cos_fma)
+RTM_FN double cos(double x) {
+    using namespace sincos_;
+    const uint32_t k = hi32(x) & 0x7FFFFFFFu;
+    if (k < 0x3E400000u) return 1.0;            // |x| < 2^-27
+    if (k < 0x3FEB6000u) return do_cos(x, 0.0); // |x| < 0.855469
+    if (k < 0x400368FDu) {                      // |x| < 2.426265: sin (pi/2 - |x|), the difference to twice the precision
+        const double y = hp0 - abs_(x);
+        const double a = y + hp1;
+        const double da = (y - a) + hp1;
+        return do_sin(a, da);
+    }
+    if (k < 0x7FF00000u) {
+        double a, da;
+        const uint32_t n = k < 0x419921FBu ? reduce_sincos(x, &a, &da) : branred(x, &a, &da);
+        return do_sincos(a, da, n + 1u);
+    }
+    return nan_();
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // acos: glibc 2.35 sysdeps/ieee754/dbl-64/e_asin.c (__ieee754_acos, IBM Accurate Mathematical Library), FMA build
 // ---------------------------------------------------------------------------------------------------------------------
@@ -497,6 +517,158 @@ RTM_FN double atan2(double y, double x) {
         }
     }
     return with_sign_of(z, y);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pow: glibc 2.35 sysdeps/ieee754/dbl-64/e_pow.c (ARM's optimized routines: log to 68 bits, then exp), __pow_fma
+// ---------------------------------------------------------------------------------------------------------------------
+namespace pow_ {
+// 0 if y is not an integer, 1 if odd, 2 if even
+RTM_FN int checkint(uint64_t iy) {
+    const int e = (int)((iy >> 52) & 0x7FF);
+    if (e < 0x3FF) return 0;
+    if (e > 0x3FF + 52) return 2;
+    if (iy & ((1ull << (0x3FF + 52 - e)) - 1)) return 0;
+    if (iy & (1ull << (0x3FF + 52 - e))) return 1;
+    return 2;
+}
+RTM_FN bool zeroinfnan(uint64_t i) { return 2 * i - 1 >= 2 * 0x7FF0000000000000ull - 1; }
+// log (x) as hi + *tail, x > 0 given by its bits (a subnormal already scaled)
+RTM_FN double log_inline(uint64_t ix, double *tail) {
+    const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
+    const double A0 = -0x1p-1, A1 = -0x1.5555555555560p-1, A2 = 0x1.0000000000006p-1, A3 = 0x1.999999959554ep-1,
+                 A4 = -0x1.555555529a47ap-1, A5 = -0x1.2495b9b4845e9p+0, A6 = 0x1.0002b8b263fc3p+0;
+    const uint64_t tmp = ix - 0x3FE6955500000000ull;
+    const uint32_t i = (uint32_t)(tmp >> 45) & 127u;
+    const int32_t k = (int32_t)((int64_t)tmp >> 52);
+    const uint64_t iz = ix - (tmp & 0xFFF0000000000000ull);
+    const double z = from_bits(iz), kd = (double)k;
+    const double invc = rtm_pow_log_tab[4 * i], logc = rtm_pow_log_tab[4 * i + 2], logctail = rtm_pow_log_tab[4 * i + 3];
+    const double r = fma_(z, invc, -1.0);
+    const double t1 = fma_(kd, Ln2hi, logc);
+    const double t2 = r + t1;
+    const double lo1 = fma_(kd, Ln2lo, logctail);
+    const double lo2 = (t1 - t2) + r;
+    const double ar = r * A0;
+    const double ar2 = r * ar;
+    const double ar3 = r * ar2;
+    const double hi = t2 + ar2;
+    const double lo3 = fma_(ar, r, -ar2);
+    const double lo4 = (t2 - hi) + ar2;
+    const double p12 = fma_(r, A2, A1), p34 = fma_(r, A4, A3), p56 = fma_(r, A6, A5);
+    const double inner = fma_(ar2, fma_(p56, ar2, p34), p12);
+    double lo = lo1 + lo2;
+    lo = lo + lo3;
+    lo = lo + lo4;
+    lo = fma_(ar3, inner, lo);
+    const double y = hi + lo;
+    *tail = (hi - y) + lo;
+    return y;
+}
+// exp (x + xtail) with the sign of sign_bias; the results that overflow or fall into the subnormal range
+RTM_FN double exp_special(double tmp, uint64_t sbits, uint64_t ki) {
+    if ((ki & 0x80000000ull) == 0) { // k > 0: the exponent of scale might have overflowed by <= 460
+        sbits -= 1009ull << 52;
+        const double scale = from_bits(sbits);
+        return 0x1p1009 * fma_(scale, tmp, scale);
+    }
+    sbits += 1022ull << 52; // k < 0: special care in the subnormal range
+    const double scale = from_bits(sbits);
+    const double st = scale * tmp;
+    double y = scale + st;
+    if (abs_(y) < 1.0) {
+        const double one = y < 0.0 ? -1.0 : 1.0;
+        double lo = (scale - y) + st;
+        const double hi = y + one;
+        lo = ((one - hi) + y) + lo;
+        y = (lo + hi) - one;
+        if (y == 0.0) y = from_bits(sbits & 0x8000000000000000ull);
+    }
+    return 0x1p-1022 * y;
+}
+RTM_FN double exp_inline(double x, double xtail, uint32_t sign_bias) {
+    const double InvLn2N = 0x1.71547652b82fep+7, Shift = 0x1.8p+52, NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47;
+    const double C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3, C4 = 0x1.55555cf172b91p-5, C5 = 0x1.1111167a4d017p-7;
+    uint32_t abstop = (uint32_t)(bits(x) >> 52) & 0x7FFu;
+    if (abstop - 0x3C9u >= 0x3Fu) {
+        if (abstop - 0x3C9u >= 0x80000000u) { // tiny: 1 + x
+            const double one = 1.0 + x;
+            return sign_bias ? -one : one;
+        }
+        if (abstop >= 0x409u) { // |x| >= 1024: the result underflows to (signed) zero or overflows to (signed) infinity
+            if (bits(x) >> 63) return sign_bias ? -0.0 : 0.0;
+            return sign_bias ? -__builtin_huge_val() : __builtin_huge_val();
+        }
+        abstop = 0u; // large x is special-cased below
+    }
+    double kd = fma_(x, InvLn2N, Shift);
+    const uint64_t ki = bits(kd);
+    kd -= Shift;
+    double r = fma_(kd, NegLn2hiN, x);
+    r = fma_(kd, NegLn2loN, r);
+    r = xtail + r;
+    const uint32_t idx = 2u * ((uint32_t)ki & 127u);
+    const uint64_t top = (ki + sign_bias) << 45;
+    const double tail = rtm_exp_tab[idx];
+    const uint64_t sbits = bits(rtm_exp_tab[idx + 1]) + top;
+    const double r2 = r * r;
+    double tmp = fma_(fma_(r, C3, C2), r2, r + tail);
+    tmp = fma_(fma_(r, C5, C4), r2 * r2, tmp);
+    if (abstop == 0u) return exp_special(tmp, sbits, ki);
+    const double scale = from_bits(sbits);
+    return fma_(tmp, scale, scale);
+}
+} // namespace pow_
+
+RTM_FN double pow(double x, double y) {
+    using namespace pow_;
+    uint32_t sign_bias = 0;
+    uint64_t ix = bits(x);
+    const uint64_t iy = bits(y);
+    uint32_t topx = (uint32_t)(ix >> 52);
+    const uint32_t topy = (uint32_t)(iy >> 52);
+    if (topx - 0x001u >= 0x7FFu - 0x001u || (topy & 0x7FFu) - 0x3BEu >= 0x43Eu - 0x3BEu) {
+        // x < 2^-1022, infinite or NaN; or |y| < 2^-65, >= 2^63 or NaN
+        if (zeroinfnan(iy)) {
+            if (2 * iy == 0) return 1.0; // (a signalling NaN x would give NaN: not told apart here)
+            if (ix == 0x3FF0000000000000ull) return 1.0;
+            if (2 * ix > 2 * 0x7FF0000000000000ull || 2 * iy > 2 * 0x7FF0000000000000ull) return x + y;
+            if (2 * ix == 2 * 0x3FF0000000000000ull) return 1.0;
+            if ((2 * ix < 2 * 0x3FF0000000000000ull) == !(iy >> 63)) return 0.0; // |x| < 1 and y = inf, or |x| > 1 and y = -inf
+            return y * y;
+        }
+        if (zeroinfnan(ix)) {
+            double x2 = x * x;
+            if ((ix >> 63) && checkint(iy) == 1) {
+                x2 = -x2;
+                sign_bias = 1;
+            }
+            if (2 * ix == 0 && (iy >> 63)) return sign_bias ? -__builtin_huge_val() : __builtin_huge_val();
+            return (iy >> 63) ? 1.0 / x2 : x2;
+        }
+        if (ix >> 63) { // finite x < 0
+            const int yint = checkint(iy);
+            if (yint == 0) return nan_();
+            if (yint == 1) sign_bias = 0x800u << 7;
+            ix &= 0x7FFFFFFFFFFFFFFFull;
+            topx &= 0x7FFu;
+        }
+        if ((topy & 0x7FFu) - 0x3BEu >= 0x43Eu - 0x3BEu) {
+            if (ix == 0x3FF0000000000000ull) return 1.0;
+            if ((topy & 0x7FFu) < 0x3BEu) return ix > 0x3FF0000000000000ull ? 1.0 + y : 1.0 - y; // |y| < 2^-65
+            return (ix > 0x3FF0000000000000ull) == (topy < 0x800u) ? __builtin_huge_val() : 0.0; // overflow / underflow
+        }
+        if (topx == 0) { // subnormal x: scale it
+            ix = bits(x * 0x1p52);
+            ix &= 0x7FFFFFFFFFFFFFFFull;
+            ix -= 52ull << 52;
+        }
+    }
+    double lo;
+    const double hi = log_inline(ix, &lo);
+    const double ehi = y * hi;
+    const double elo = fma_(y, lo, fma_(hi, y, -ehi));
+    return exp_inline(ehi, elo, sign_bias);
 }
 
 } // namespace rtm

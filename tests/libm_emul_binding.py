@@ -11,7 +11,7 @@ _L.libm_emul_count_diffs.restype = C.c_int64
 _L.libm_emul_count_diffs.argtypes = [C.c_int, _P, _P, C.c_int64, C.POINTER(C.c_int64)]
 _L.libm_emul_eval.restype = None
 _L.libm_emul_eval.argtypes = [C.c_int, _P, _P, C.c_int64, _P, _P]
-FUNCTIONS = ("log", "sin", "acos", "atan2")
+FUNCTIONS = ("log", "sin", "acos", "atan2", "cos", "pow")
 
 
 def _arr(a):

@@ -48,6 +48,11 @@ def test_device_libm_returns_the_host_libm_bits(rt, gpu_device, lane_emul):
         "atan2": [(v[:, 0].copy(), v[:, 2].copy()), (rng.normal(size=n), rng.normal(size=n)),
                   (np.exp(rng.uniform(-700.0, 700.0, n)) * sg(), np.exp(rng.uniform(-700.0, 700.0, n)) * sg()),
                   (rng.uniform(0.0, 1.0, n) * sg(), sg()), (sg(), rng.uniform(0.0, 1.0, n) * sg()), (bits(), bits())],
+        # restated and pinned like the four the kernels call (Dielectric's `cos` and `powf`, see rt_lane.h schlick_reflects)
+        "cos": [(rng.uniform(-2.5, 2.5, n),), (np.arccos(rng.uniform(-1.0, 1.0, n)),), (rng.uniform(-1.1e8, 1.1e8, n),), (bits(),)],
+        "pow": [(rng.uniform(-1.0, 1.0, n), np.full(n, 2.0)), (rng.uniform(0.0, 2.0, n), np.full(n, 5.0)),
+                (np.exp(rng.uniform(-700.0, 700.0, n)), rng.uniform(-300.0, 300.0, n)), (-np.exp(rng.uniform(-5.0, 5.0, n)), rng.integers(-40, 40, n).astype(np.float64)),
+                (bits(), bits())],
     }
     for which, sets in cases.items():
         for k, args in enumerate(sets):
