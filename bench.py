@@ -74,7 +74,7 @@ def parse():
                     help="sum each step's sample records on the render stream instead of behind it (RT_FLAG_DEFERRED_OUTPUT off): "
                          "reduce_kernel (HBM-bound) then no longer overlaps the next step's render_kernel (VALU-bound)")
     ap.add_argument("--pipeline", action="store_true",
-                    help="experiment: consecutive steps on two alternating streams (measured slower, see DESIGN.md section 8)")
+                    help="experiment: consecutive steps on two alternating streams (measured slower, see docs/experiments.md section 2)")
     return ap.parse_args()
 
 

@@ -1,7 +1,7 @@
 // rt_lds.h -- THE layout of render_kernel's dynamic LDS, one definition for the host (rt_api.cpp sizes the launch with
 // it) and the device (rt_kernels.hip carves the regions out of it).
 //
-// Why it exists ("the 05:58 abort of round 2"): the kernel placed a new region (the waves' job state)
+// Why it exists (docs/experiments.md section 2, "the 05:58 abort of round 2"): the kernel placed a new region (the waves' job state)
 // between the node copy and the swap queues while the host still sized the launch without it; the queues' last 128 bytes then
 // lay outside the workgroup's allocation and aliased the next workgroup's traversal stack -- a persistent kernel whose
 // waves only leave when their paths are finished turns that into a hang, not a wrong pixel.  With one function there is no
@@ -27,7 +27,7 @@
 #define RT_SWAP_CLASSES 3  /* lambertian, metal, dielectric (RT_MAT_* values 0..2): queues of finished segments waiting to be scattered */
 // A fourth queue in the same format -- rays whose next segment has been set up and that wait for a lane, so that lanes which finish
 // their traversal early park their hit and take one instead of idling until the wave's shade quorum -- was built and measured in
-// round 3 (profiles/r03_experiments/ray_exchange_kernel.patch): slower on every scene (cornell 2533 -> 2282,
+// round 3 (profiles/r03_experiments/ray_exchange_kernel.patch, docs/experiments.md section 2): slower on every scene (cornell 2533 -> 2282,
 // cover 2121 -> 2077 Msamples/s).  The layout has the three class queues and nothing else: there is no queue count for the host and
 // the kernel to disagree about.
 #define RT_SWAP_F64 14     /* o, d, T (9), s0, s1, best_t, draws, base */
