@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--check", action="store_true", help="rank 0 also renders the whole image alone and compares (default for N > 1)")
     ap.add_argument("--no-check", action="store_true", help="skip that comparison for N > 1")
+    ap.add_argument("--ascending-tiles", action="store_true",
+                    help="N > 1: hand every shard's tiles out in ascending order instead of the learnt deepest-first order (A/B)")
     ap.add_argument("--no-defer", action="store_true",
                     help="sum each step's sample records on the render stream instead of behind it (RT_FLAG_DEFERRED_OUTPUT off): "
                          "reduce_kernel (HBM-bound) then no longer overlaps the next step's render_kernel (VALU-bound)")
@@ -278,6 +280,8 @@ def main():
     # default (deferred output): ONE render stream -- render kernels never overlap each other -- and everything behind a render
     # kernel (the sums of its sample records, gather, unpack, copy) on a second stream, overlapping the next step's render
     defer = not a.no_defer and not a.pipeline
+    # N > 1: a shard's tiles go out deepest first, in an order the library learns from the first render of the view (the warm-up)
+    order_flag = rt.RT_FLAG_ASCENDING_TILES if a.ascending_tiles else 0
     n_buf = 2 if (a.pipeline or defer) else 1
     mines = [torch.zeros(pad_tiles * 64 * 3, dtype=torch.float64, device=dev) for _ in range(n_buf)]
     gathereds = [torch.zeros(world * pad_tiles * 64 * 3, dtype=torch.float64, device=dev) if rank == 0 else None for _ in range(n_buf)]
@@ -311,7 +315,7 @@ def main():
             rs.wait_event(post_done[k % 2])  # step k - 2 has finished reading mine_k / gathered_k
             mark("start", rs)
             sc.render_tiles_device(cam, W, H, spp, depth, a.seed, (rank, world), mine_k.data_ptr(), None, rs.cuda_stream,
-                                   flags=rt.RT_FLAG_DEFERRED_OUTPUT)
+                                   flags=rt.RT_FLAG_DEFERRED_OUTPUT | order_flag)
             mark("render", rs)
             sc.wait_output(post_stream.cuda_stream)  # the post stream waits for this step's sums
             rs = post_stream
@@ -319,7 +323,7 @@ def main():
             stream = rs.cuda_stream
             if not defer:
                 mark("start", rs)
-                sc.render_tiles_device(cam, W, H, spp, depth, a.seed, (rank, world), mine_k.data_ptr(), None, stream)
+                sc.render_tiles_device(cam, W, H, spp, depth, a.seed, (rank, world), mine_k.data_ptr(), None, stream, flags=order_flag)
                 mark("render", rs)
             if world > 1 and a.backend == "nccl":
                 glist = list(gathered_k.chunk(world)) if rank == 0 else None
@@ -361,6 +365,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     last_kernel_ms = sc.last_kernel_ms()
+    tile_order_mode = sc.last_launch_config()["tile_order"]  # of the last timed step
 
     # one more, UNTIMED step with events after every stage (per-rank anatomy of a step)
     marks = []
@@ -370,6 +375,7 @@ def main():
     for (n0, e0), (n1, e1) in zip(marks, marks[1:]):
         anatomy[n1 + "_ms"] = e0.elapsed_time(e1)
     anatomy["render_kernel_ms"] = sc.last_kernel_ms()
+    anatomy["tile_order"] = tile_order_mode
 
     # per-launch kernel duration measured with HIP events on the launch stream: time each launch separately, untimed loop
     # ... and ONE render on its own, nothing beside it: render_kernel, then the sums of its sample records on the same stream
@@ -379,7 +385,7 @@ def main():
         cur = torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(cur)
-        sc.render_tiles_device(cam, W, H, spp, depth, a.seed, (rank, world), mine.data_ptr(), None, cur.cuda_stream)
+        sc.render_tiles_device(cam, W, H, spp, depth, a.seed, (rank, world), mine.data_ptr(), None, cur.cuda_stream, flags=order_flag)
         e1.record(cur)
         torch.cuda.synchronize()
         per_launch.append(sc.last_kernel_ms())
@@ -443,7 +449,10 @@ def main():
                        "scene_seed": a.scene_seed, "render_seed": a.seed, "n_prims": info["n_prims"],
                        "bvh_nodes": info["n_nodes"], "sharding": f"8x8 tiles, tile_id % {world}, one RCCL gather",
                        "library": rt.version(), "steps_pipelined_on_two_streams": bool(a.pipeline),
-                       "sums_behind_the_next_render": bool(defer)},
+                       "sums_behind_the_next_render": bool(defer),
+                       "tile_order": {0: "ascending" + (" (a whole image always is)" if world == 1 else ""),
+                                      1: "learnt from the warm-up's path lengths: deepest tiles first",
+                                      2: "ascending (still learning: fewer than two warm-up steps)"}[tile_order_mode]},
             # `value` is the pipelined figure (a step's sums run beside the next step's render); one image rendered alone:
             "single_render_ms": single_render_ms, "single_render_msamples_per_s": total_samples / (single_render_ms * 1e-3) / 1e6,
             "single_render_note": "one rt_render_tiles_device on its own (render_kernel + reduce_kernel on one stream, slowest rank), "

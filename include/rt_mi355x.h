@@ -153,6 +153,7 @@ typedef struct rt_render_params {
 #define RT_TILE 8                 /* tile edge in pixels */
 #define RT_FLAG_COUNTERS 1u       /* also accumulate rt_counters (slower build of the kernel) */
 #define RT_FLAG_DEFERRED_OUTPUT 2u /* rt_render_tiles_device only: see rt_render_wait_output */
+#define RT_FLAG_ASCENDING_TILES 4u /* hand the owned tiles out in ascending order: neither use nor learn a tile order (below) */
 
 typedef struct rt_counters {
     uint64_t samples, segments, nodes_visited, prims_tested, rng_draws;
@@ -256,8 +257,21 @@ typedef struct rt_launch_config {
     int lds_nodes, swap;
     size_t workspace_bytes;
     int swap_cap, waves_per_simd; /* entries per swap queue; waves per SIMD the kernel family is compiled for */
+    int tile_order;               /* RT_TILE_ORDER_* */
 } rt_launch_config;
 int rt_last_launch_config(rt_scene *, rt_launch_config *out);
+/* A render of a SHARD (shard_count > 1) hands its tiles to the waves deepest first: the few 100-segment paths that finish a launch
+ * alone (a fixed ~1 ms, 12 % of a 1/8 shard of book-one) then start early and the launch ends on shallow tiles.  The order is learnt:
+ * the first render of a view (camera, size, shard, depth) adds up the path lengths per tile beside its sums and sorts the tiles; later
+ * renders of the same view use that order as soon as it is complete (never waiting for it).  The image does not depend on the order
+ * (the reference deals rows to threads in no particular order either, examples/book-one.rs:56-65).  A whole image (shard_count 1)
+ * is always rendered in ascending order (neighbouring tiles share rays: faster there). */
+#define RT_TILE_ORDER_ASCENDING 0
+#define RT_TILE_ORDER_LEARNT 1   /* this render used a learnt order */
+#define RT_TILE_ORDER_LEARNING 2 /* this render ran in ascending order and learns the order of its view */
+/* the learnt order of the scene's current view, once complete (waits for the device): n owned tiles written to order_out (owned-tile
+ * indices, first handed out first) and their summed path lengths to cost_out (indexed by owned tile); 0 when there is none */
+int rt_scene_tile_order(rt_scene *, uint32_t *order_out, uint64_t *cost_out, int capacity);
 
 /* ---- output: tone map + P3 text of the drivers (examples/book-one.rs:28-30,90-100):
  *      gamma 2, clamp high, truncate, NaN / negative -> 255 (Q13); rows top-down ---- */

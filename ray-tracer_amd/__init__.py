@@ -27,6 +27,8 @@ LIB_PATH = Path(os.environ.get("RT_MI355X_LIB") or (_HERE / "lib" / "librt_mi355
 RT_TILE = 8
 RT_FLAG_COUNTERS = 1
 RT_FLAG_DEFERRED_OUTPUT = 2
+RT_FLAG_ASCENDING_TILES = 4
+RT_TILE_ORDER_ASCENDING, RT_TILE_ORDER_LEARNT, RT_TILE_ORDER_LEARNING = 0, 1, 2
 RT_FEAT_SPHERE_T, RT_FEAT_GENERAL, RT_FEAT_MEDIUM, RT_FEAT_TEXTURED, RT_FEAT_LENS, RT_FEAT_MEDIUM_GENERAL, RT_FEAT_WIDE = 1, 2, 4, 8, 16, 32, 64
 RT_FEAT_DEEP_CHAIN = FEAT_DEEP_CHAIN = 128
 RT_FEAT_MEDIUM_NESTED = 256
@@ -76,7 +78,7 @@ class rt_launch_config(C.Structure):
     _fields_ = [("blocks", C.c_int), ("block_threads", C.c_int), ("lds_bytes", C.c_uint), ("blocks_per_cu", C.c_int),
                 ("n_cu", C.c_int), ("passes", C.c_int), ("n_jobs", C.c_int), ("job_spp", C.c_int),
                 ("kernel_features", C.c_uint), ("lds_nodes", C.c_int), ("swap", C.c_int), ("workspace_bytes", C.c_size_t),
-                ("swap_cap", C.c_int), ("waves_per_simd", C.c_int)]
+                ("swap_cap", C.c_int), ("waves_per_simd", C.c_int), ("tile_order", C.c_int)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -132,6 +134,7 @@ ABI = {
     "rt_scene_workspace_bytes": (C.c_size_t, [_VP]),
     "rt_last_kernel_ms": (C.c_int, [_VP, C.POINTER(C.c_float)]),
     "rt_last_launch_config": (C.c_int, [_VP, C.POINTER(rt_launch_config)]),
+    "rt_scene_tile_order": (C.c_int, [_VP, _VP, _VP, C.c_int]),
     "rt_tonemap_rgb8": (None, [_DP, C.c_size_t, C.POINTER(C.c_uint8)]),
     "rt_write_ppm_p3": (C.c_int, [C.c_char_p, _DP, C.c_int, C.c_int]),
     "rt_write_png_rgba8": (C.c_int, [C.c_char_p, _DP, C.c_int, C.c_int]),
@@ -147,6 +150,27 @@ ABI = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  The library needs `libamdhip64.so.7`; PyTorch-ROCm brings its own copy and asks for it as
+    `libamdhip64.so`, so a process that loads this library BEFORE importing torch ends up with two runtimes, and the one
+    initialised second finds no GPU (seen on the MI355X box: "No HIP GPUs are available" from torch after the library's first
+    render).  Loaded first, torch's copy carries the soname this library asks for and both share it -- so when torch is installed
+    but not imported yet, its runtime is loaded here (torch itself is not imported)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    hip = Path(spec.origin).parent / "lib" / "libamdhip64.so"
+    if hip.exists():
+        C.CDLL(str(hip), mode=C.RTLD_GLOBAL)
+
+
 def lib() -> C.CDLL:
     """Load librt_mi355x.so (fails loudly if it has not been built)."""
     global _lib
@@ -155,6 +179,7 @@ def lib() -> C.CDLL:
             raise FileNotFoundError(
                 f"{LIB_PATH} is missing: build it with `make -C ray-tracer_amd/csrc` "
                 "(or __graft_entry__.build()); there is no fallback path")
+        _share_torch_hip_runtime()
         L = C.CDLL(str(LIB_PATH))
         for name, (res, args) in ABI.items():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
@@ -376,6 +401,16 @@ class Scene:
         lc = rt_launch_config()
         _check(lib().rt_last_launch_config(self._h, C.byref(lc)))
         return lc.as_dict()
+
+    def tile_order(self, capacity: int = 65536):
+        """the learnt hand-out order of the owned tiles of the current view and the tiles' summed path lengths
+        (rt_scene_tile_order; waits for the device), or None when there is none"""
+        order = np.zeros(capacity, dtype=np.uint32)
+        cost = np.zeros(capacity, dtype=np.uint64)
+        n = lib().rt_scene_tile_order(self._h, order.ctypes.data_as(C.c_void_p), cost.ctypes.data_as(C.c_void_p), capacity)
+        if n < 0:
+            _check(n)
+        return None if n == 0 else (order[:n].copy(), cost[:n].copy())
 
 
 class Camera:

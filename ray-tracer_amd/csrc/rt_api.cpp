@@ -25,7 +25,9 @@
 extern "C" int rt_launch_render(const RtLaunch *L, unsigned features, int lens, int count, int ldsnodes, int blocks,
                                 unsigned lds_bytes, void *stream);
 extern "C" int rt_launch_reduce(const double *samples, double *tiles, int n_owned_tiles, int s_count, int first_pass, int last_pass,
-                                int spp, int width, int height, int shard_index, int shard_count, int narrow_blocks, void *stream);
+                                int spp, int width, int height, int shard_index, int shard_count, int narrow_blocks,
+                                unsigned long long *tile_cost, void *stream);
+extern "C" int rt_launch_tile_order(const unsigned long long *tile_cost, int n, int levels, unsigned int *order, void *stream);
 extern "C" int rt_kernel_block_size(unsigned features);
 extern "C" int rt_kernel_waves_per_simd(unsigned features);
 extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int ldsnodes, unsigned lds_bytes, int *blocks_per_cu,
@@ -376,6 +378,18 @@ static int check_device_status(rt_scene::RenderSlot &sl) {
     return fail(RT_ERR_DEVICE, "device error word " + std::to_string(st) + ":" + what + " the image is incomplete");
 }
 
+// what a learnt tile order belongs to: the view (never 0)
+static uint64_t view_key(const rt_camera *cam, const rt_render_params *p) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    auto eat = [&](const void *q, size_t n) {
+        for (size_t i = 0; i < n; ++i) h = (h ^ ((const unsigned char *)q)[i]) * 0x100000001B3ull;
+    };
+    eat(cam, sizeof *cam); // thirteen doubles, no padding
+    const int v[5] = {p->width, p->height, p->shard_index, p->shard_count, p->max_depth};
+    eat(v, sizeof v);
+    return h | 1ull;
+}
+
 // Render samples [s_begin, s_end) of every owned pixel.  accumulate: the tile buffer already holds the
 // raw sums of samples [0, s_begin) and is continued in sample order; finalize: divide by spp at the end.
 static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_params *p, int s_begin, int s_end, bool accumulate,
@@ -494,6 +508,42 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
 #endif
     }
     L.counters = count ? (RtCounters *)d_counters : nullptr;
+    // hand-out order of the owned tiles (include/rt_mi355x.h RT_TILE_ORDER_*): shards only, learnt once per view
+    int order_mode = RT_TILE_ORDER_ASCENDING;
+    uint64_t order_key = 0;
+    rt_scene::TileOrder &to = s->tile_order;
+    int order_levels = 0;
+    bool order_whole = false;
+#if defined(RT_TEST_HOOKS) // experiments (tools/tile_order_probe.py)
+    if (const char *t = std::getenv("RT_TEST_TILE_ORDER_LEVELS")) order_levels = std::atoi(t);
+    if (const char *t = std::getenv("RT_TEST_TILE_ORDER_WHOLE")) order_whole = *t == '1';
+#endif
+    if ((p->shard_count > 1 || order_whole) && !(p->flags & RT_FLAG_ASCENDING_TILES) && !accumulate && finalize && n_owned >= 64 && n_owned <= 65536) {
+        order_key = view_key(cam, p);
+        if (to.key == order_key && to.n == n_owned) {
+            if (!to.complete && hipEventQuery(to.ready) == hipSuccess) to.complete = true;
+            if (to.complete) {
+                L.tile_order = (const unsigned int *)to.d_order;
+                order_mode = RT_TILE_ORDER_LEARNT;
+            } // else: the render that learns it is still in flight -- ascending, and no second learner
+        } else {
+            if (n_owned > to.capacity) {
+                HIP_TRY(hipDeviceSynchronize()); // an earlier render may still read the old table
+                if (to.d_cost) HIP_TRY(hipFree(to.d_cost));
+                if (to.d_order) HIP_TRY(hipFree(to.d_order));
+                to.d_cost = to.d_order = nullptr;
+                to.capacity = 0;
+                HIP_TRY(hipMalloc(&to.d_cost, (size_t)n_owned * sizeof(uint64_t)));
+                HIP_TRY(hipMalloc(&to.d_order, (size_t)n_owned * sizeof(uint32_t)));
+                to.capacity = n_owned;
+            }
+            if (!to.ready) HIP_TRY(hipEventCreateWithFlags(&to.ready, hipEventDisableTiming));
+            to.key = 0; // no view owns the table until this render's `ready` has been recorded
+            to.complete = false;
+            order_mode = RT_TILE_ORDER_LEARNING;
+        }
+    }
+    const bool learning = order_mode == RT_TILE_ORDER_LEARNING;
     const int n_pass = (n_spp + chunk - 1) / chunk;
     int last_blocks = 0;
     while ((int)sl.events.size() < 2 * n_pass) {
@@ -539,10 +589,24 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
         // deferred: ONE 256-thread group per CU (grid-stride) = one wave per SIMD = the 32 VGPRs that four render waves of 120 leave
         // free, so the next render_kernel's two workgroups per CU are resident beside it (book-one 1200x800x500: 64.75 ms per step
         // against 65.85 with the sums on the render stream; two groups per CU, or a reduce_kernel of 36 VGPRs: 65.2)
+        if (learning && pass == 0) {
+            // the table is written behind EVERY earlier render of this scene (a reader of the old order, or its learner)
+            for (rt_scene::RenderSlot &o : s->slots)
+                if (o.used && o.done) HIP_TRY(hipStreamWaitEvent(rs, o.done, 0));
+            HIP_TRY(hipMemsetAsync(to.d_cost, 0, (size_t)n_owned * sizeof(uint64_t), rs));
+        }
         rc = rt_launch_reduce(L.samples, (double *)d_tiles_out, n_owned, L.s_count, pass == 0 && !accumulate,
                               pass == n_pass - 1 && finalize, p->spp, p->width,
-                              p->height, p->shard_index, p->shard_count, defer ? n_cu : 0, (void *)rs);
+                              p->height, p->shard_index, p->shard_count, defer ? n_cu : 0,
+                              learning ? (unsigned long long *)to.d_cost : nullptr, (void *)rs);
         if (rc != 0) return hip_fail((hipError_t)rc, "reduce_kernel launch");
+        if (learning && pass == n_pass - 1) {
+            rc = rt_launch_tile_order((const unsigned long long *)to.d_cost, n_owned, order_levels, (unsigned int *)to.d_order, (void *)rs);
+            if (rc != 0) return hip_fail((hipError_t)rc, "tile_order_kernel launch");
+            HIP_TRY(hipEventRecord(to.ready, rs));
+            to.key = order_key;
+            to.n = n_owned;
+        }
         if (defer) {
             HIP_TRY(hipEventRecord(sl.done, rs));
             sl.used = true;
@@ -568,6 +632,7 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     lc.workspace_bytes = need;
     lc.swap_cap = (int)swap_cap;
     lc.waves_per_simd = rt_kernel_waves_per_simd(feat);
+    lc.tile_order = order_mode;
     return RT_OK;
 }
 
@@ -695,6 +760,19 @@ int rt_last_launch_config(rt_scene *s, rt_launch_config *out) {
     if (!s->timed) return fail(RT_ERR_STATE, "no render has been launched on this scene");
     *out = s->last_launch;
     return RT_OK;
+}
+
+int rt_scene_tile_order(rt_scene *s, uint32_t *order_out, uint64_t *cost_out, int capacity) {
+    if (!s || !order_out || !cost_out) return fail(RT_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
+    const rt_scene::TileOrder &to = s->tile_order;
+    if (to.key == 0 || to.n == 0) return 0;
+    if (capacity < to.n) return fail(RT_ERR_INVALID, "rt_scene_tile_order: capacity below the number of owned tiles");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventSynchronize(to.ready));
+    HIP_TRY(hipMemcpy(order_out, to.d_order, (size_t)to.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cost_out, to.d_cost, (size_t)to.n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return to.n;
 }
 
 int rt_render(rt_scene *s, const rt_camera *cam, const rt_render_params *p, double *out_rgb, rt_counters *counters) {

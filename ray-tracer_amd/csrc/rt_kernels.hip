@@ -208,10 +208,11 @@ __host__ __device__ constexpr int waves_of(bool general, int medium) {
 #ifndef RT_NT_STORE
 #define RT_NT_STORE 1
 #endif
-__device__ __forceinline__ void store_sample(double *samples, uint32_t slot, rtl::V3 rad) {
+// (the record's fourth word: the path's length in segments, an integer in the low half -- what a learnt tile order is made of)
+__device__ __forceinline__ void store_sample(double *samples, uint32_t slot, rtl::V3 rad, int32_t segments) {
     typedef double v2d __attribute__((ext_vector_type(2)));
     v2d *o = reinterpret_cast<v2d *>(samples + (size_t)slot * 4);
-    const v2d a = {rad.x, rad.y}, b = {rad.z, 0.0};
+    const v2d a = {rad.x, rad.y}, b = {rad.z, __builtin_bit_cast(double, (unsigned long long)(uint32_t)segments)};
 #if defined(RT_PROBE_NO_SAMPLE_STORE) // timing experiment only (wrong images): what the sample-record stream costs render_kernel at most
     if (!(rad.x == -1.2345e300)) return;
 #endif
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                     } else {
                         rtl::V3 rad = rtl::mk(0.0, 0.0, 0.0);
                         if (kind == RT_MAT_DIFFUSE_LIGHT) rad = ps.T * rtl::ld3(((GENERAL || MEDIUM) ? rtl::rec_at(L.materials, mat) : L.materials[mat]).rgb); // finish_segment's T * emit
-                        store_sample(L.samples, slot, rad);
+                        store_sample(L.samples, slot, rad, ps.k);
                         has_path = false;
                         cls = kEmpty;
                         if (COUNT) {
@@ -566,7 +567,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                         if (mode_new || cls != cstar) ++w_off;
                     }
                     if (fin) {
-                        store_sample(L.samples, slot, rad);
+                        store_sample(L.samples, slot, rad, ps.k);
                         has_path = false;
                         if (COUNT) {
                             c_draws += ps.g.draws;
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                     if (fin) {
                         // one 32-byte aligned record per sample, two 16-byte stores: whole sectors,
                         // no read-modify-write of partially written lines at the memory side
-                        store_sample(L.samples, slot, rad);
+                        store_sample(L.samples, slot, rad, ps.k);
                         has_path = false;
                         if (COUNT) {
                             c_draws += ps.g.draws;
@@ -634,7 +635,9 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                     }
                     const uint32_t jobs_per_tile = (uint32_t)K->jobs_per_tile, tiles_x = (uint32_t)K->tiles_x, s_count = (uint32_t)K->s_count,
                                    job_spp = (uint32_t)K->job_spp;
-                    const uint32_t k = j / jobs_per_tile, sub = j - k * jobs_per_tile;
+                    const uint32_t kj = j / jobs_per_tile, sub = j - kj * jobs_per_tile;
+                    const unsigned int *order = K->tile_order; // (wave-uniform: scalar loads)
+                    const uint32_t k = order ? order[kj] : kj;
                     const uint32_t tile = (uint32_t)K->shard_index + k * (uint32_t)K->shard_count;
                     const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
                     job_x0 = tx * RT_TILE_EDGE;
@@ -787,8 +790,12 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
 // Sum this pass's samples in sample order on top of the running sums; the last
 // pass divides by spp (`pixel /= subPixelSampleCount`, examples/book-one.rs:76).
 // One thread per owned pixel; consecutive threads read consecutive 32-byte records.
+// COST (a render that learns its tile order, once per view: rt_api.cpp): also add up the records' fourth words, the path lengths,
+// per tile (one atomic per pixel and pass).
+template <bool COST>
 __global__ void reduce_kernel(const double *samples, double *tiles, int n_owned_tiles, int s_count, int first_pass,
-                              int last_pass, int spp, int width, int height, int tiles_x, int shard_index, int shard_count) {
+                              int last_pass, int spp, int width, int height, int tiles_x, int shard_index, int shard_count,
+                              unsigned long long *tile_cost) {
     // grid-stride over the owned pixels: the launch may be the whole image (one thread per pixel) or NARROW (two 256-thread
     // groups per CU, each thread several pixels) -- the narrow form leaves the CUs to a render_kernel that runs beside it
     // (RT_FLAG_DEFERRED_OUTPUT) and still reaches the HBM roof (131 k threads x two records in flight)
@@ -803,6 +810,7 @@ __global__ void reduce_kernel(const double *samples, double *tiles, int n_owned_
             out[0] = out[1] = out[2] = 0.0;
             continue;
         }
+        unsigned long long cost = 0ull;
         double r = 0.0, g = 0.0, b = 0.0;
         if (!first_pass) {
             r = out[0];
@@ -818,8 +826,10 @@ __global__ void reduce_kernel(const double *samples, double *tiles, int n_owned_
             r += a.x;
             g += a.y;
             b += c.x;
+            if (COST) cost += (unsigned long long)(uint32_t)__builtin_bit_cast(unsigned long long, c.y);
             p += RT_TILE_PIXELS * 2;
         }
+        if (COST) atomicAdd(&tile_cost[k], cost);
         if (last_pass) {
             const double n = (double)spp;
             r /= n;
@@ -830,6 +840,27 @@ __global__ void reduce_kernel(const double *samples, double *tiles, int n_owned_
         out[1] = g;
         out[2] = b;
     }
+}
+
+// The hand-out order of a later render of the same view: owned tiles by descending cost (ties: ascending index), by counting --
+// thread i finds the rank of tile i among all n (n <= 65536 owned tiles: a few hundred microseconds, once per view).
+// levels > 0: the costs are compared in that many equal steps of the largest one, so that tiles of about the same depth keep their
+// ascending order (neighbouring tiles share the rays' neighbourhoods).
+__global__ void tile_order_kernel(const unsigned long long *tile_cost, int n, int levels, unsigned int *order) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long top = 0ull;
+    if (levels > 0)
+        for (int j = 0; j < n; ++j) top = max(top, tile_cost[j]);
+    const unsigned long long step = levels > 0 ? top / (unsigned long long)levels + 1ull : 1ull;
+    auto key = [&](unsigned long long c) { return c / step; };
+    const unsigned long long mine = key(tile_cost[i]);
+    unsigned int rank = 0u;
+    for (int j = 0; j < n; ++j) {
+        const unsigned long long c = key(tile_cost[j]);
+        rank += (c > mine || (c == mine && j < i)) ? 1u : 0u;
+    }
+    order[rank] = (unsigned int)i;
 }
 
 // gathered shards -> row-major image.  One thread per (pixel, channel).
@@ -1001,14 +1032,26 @@ extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int 
 }
 
 // narrow_blocks > 0: that many 256-thread groups (grid-stride) instead of one thread per pixel
+// tile_cost: null, or n_owned_tiles sums of path lengths to add this pass's to
 extern "C" int rt_launch_reduce(const double *samples, double *tiles, int n_owned_tiles, int s_count, int first_pass, int last_pass,
-                                int spp, int width, int height, int shard_index, int shard_count, int narrow_blocks, void *stream) {
+                                int spp, int width, int height, int shard_index, int shard_count, int narrow_blocks,
+                                unsigned long long *tile_cost, void *stream) {
     const size_t n = (size_t)n_owned_tiles * RT_TILE_PIXELS;
     const int tiles_x = (width + RT_TILE_EDGE - 1) / RT_TILE_EDGE;
     size_t blocks = (n + 255) / 256;
     if (narrow_blocks > 0 && (size_t)narrow_blocks < blocks) blocks = (size_t)narrow_blocks;
-    hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, samples, tiles,
-                       n_owned_tiles, s_count, first_pass, last_pass, spp, width, height, tiles_x, shard_index, shard_count);
+    if (tile_cost)
+        hipLaunchKernelGGL(reduce_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, samples, tiles, n_owned_tiles,
+                           s_count, first_pass, last_pass, spp, width, height, tiles_x, shard_index, shard_count, tile_cost);
+    else
+        hipLaunchKernelGGL(reduce_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, samples, tiles, n_owned_tiles,
+                           s_count, first_pass, last_pass, spp, width, height, tiles_x, shard_index, shard_count, tile_cost);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int rt_launch_tile_order(const unsigned long long *tile_cost, int n, int levels, unsigned int *order, void *stream) {
+    hipLaunchKernelGGL(tile_order_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tile_cost, n, levels, order);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

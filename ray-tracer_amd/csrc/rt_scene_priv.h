@@ -43,6 +43,15 @@ struct rt_scene {
         int events_used = 0;
     };
     hipStream_t post_stream = nullptr; // deferred reduce_kernel launches
+    // the learnt hand-out order of the owned tiles of ONE view (include/rt_mi355x.h RT_TILE_ORDER_*): written once by the render
+    // that learns it (behind both slots' earlier renders), read by later renders of the same view only after `ready` has fired
+    struct TileOrder {
+        void *d_cost = nullptr, *d_order = nullptr; // n uint64 sums of path lengths; n uint32 owned-tile indices
+        int capacity = 0, n = 0;
+        uint64_t key = 0;   // of the view it belongs to (0: none)
+        bool complete = false; // `ready` has been seen fired
+        hipEvent_t ready = nullptr;
+    } tile_order;
     RenderSlot slots[2];
     int last_slot = 0;
     bool timed = false;
@@ -57,6 +66,10 @@ struct rt_scene {
             }
             if (post_stream) (void)hipStreamDestroy(post_stream);
             post_stream = nullptr;
+            if (tile_order.d_cost) (void)hipFree(tile_order.d_cost);
+            if (tile_order.d_order) (void)hipFree(tile_order.d_order);
+            if (tile_order.ready) (void)hipEventDestroy(tile_order.ready);
+            tile_order = TileOrder();
             for (RenderSlot &sl : slots) {
                 if (sl.d_samples) (void)hipFree(sl.d_samples);
                 if (sl.d_job_counter) (void)hipFree(sl.d_job_counter);

@@ -180,6 +180,10 @@ struct RtLaunch {
     unsigned int *job_counter; // zeroed before the launch
     double *samples;           // per-sample radiance of this pass: [owned tile][s - s0][pixel][4] (32-byte records)
     RtCounters *counters;      // may be null
+    // hand-out order of the owned tiles: null = ascending; else the k-th tile handed out is owned tile tile_order[k] (a
+    // permutation of 0 .. n_owned - 1, learnt from the path lengths of an earlier render of the same view: rt_api.cpp).
+    // A sample's slot and stream belong to its TILE, so the image does not depend on the order.
+    const unsigned int *tile_order;
 };
 
 #endif

@@ -81,6 +81,7 @@ pub struct rt_launch_config {
     pub workspace_bytes: usize,
     pub swap_cap: c_int,
     pub waves_per_simd: c_int,
+    pub tile_order: c_int,
 }
 
 #[repr(C)]
@@ -111,6 +112,10 @@ pub const RT_ERR_STATE: c_int = -5;
 pub const RT_TILE: c_int = 8;
 pub const RT_FLAG_COUNTERS: c_uint = 1;
 pub const RT_FLAG_DEFERRED_OUTPUT: c_uint = 2;
+pub const RT_FLAG_ASCENDING_TILES: c_uint = 4;
+pub const RT_TILE_ORDER_ASCENDING: c_int = 0;
+pub const RT_TILE_ORDER_LEARNT: c_int = 1;
+pub const RT_TILE_ORDER_LEARNING: c_int = 2;
 
 extern "C" {
     pub fn rt_last_error() -> *const c_char;
@@ -222,6 +227,7 @@ extern "C" {
     pub fn rt_scene_workspace_bytes(s: *const rt_scene) -> usize;
     pub fn rt_last_kernel_ms(s: *mut rt_scene, ms: *mut c_float) -> c_int;
     pub fn rt_last_launch_config(s: *mut rt_scene, out: *mut rt_launch_config) -> c_int;
+    pub fn rt_scene_tile_order(s: *mut rt_scene, order_out: *mut u32, cost_out: *mut u64, capacity: c_int) -> c_int;
 
     pub fn rt_tonemap_rgb8(rgb: *const c_double, n_pixels: usize, out_rgb8: *mut u8);
     pub fn rt_write_ppm_p3(path: *const c_char, rgb: *const c_double, w: c_int, h: c_int) -> c_int;

@@ -848,6 +848,59 @@ def test_deferred_output_overlaps_renders_and_changes_nothing(rt, scenes, gpu_de
     assert np.array_equal(imgs[0].cpu().numpy().reshape(H, W, 3), want[0])
 
 
+def test_a_shard_learns_its_tile_order_and_the_image_does_not_change(rt, scenes, gpu_device):
+    """A shard (shard_count > 1) hands its tiles out deepest first, in an order learnt from the path lengths of the first render of
+    the view (include/rt_mi355x.h RT_TILE_ORDER_*): the first render learns, later ones use the order, RT_FLAG_ASCENDING_TILES
+    switches it off, another view learns again, a whole image never has one -- and every one of them is the same picture."""
+    import torch
+    W, H, spp, depth, world = 480, 320, 16, 50, 4
+    sc, cam = scenes.build_product(scenes.book_one(1, W / H), device=gpu_device)
+    dev = torch.device("cuda", gpu_device)
+    n = rt.shard_tile_count(W, H, 1, world)
+    assert n >= 64
+    stream = torch.cuda.current_stream()
+
+    def shard(index, flags=0, seed=1, camera=cam):
+        buf = torch.zeros(rt.shard_tile_count(W, H, index, world) * 64 * 3, dtype=torch.float64, device=dev)
+        sc.render_tiles_device(camera, W, H, spp, depth, seed, (index, world), buf.data_ptr(), None, stream.cuda_stream, flags=flags)
+        if flags & rt.RT_FLAG_DEFERRED_OUTPUT:
+            sc.wait_output(stream.cuda_stream)
+        mode = sc.last_launch_config()["tile_order"]
+        torch.cuda.synchronize()
+        return buf.cpu().numpy(), mode
+
+    plain, mode = shard(1, rt.RT_FLAG_ASCENDING_TILES)
+    assert mode == rt.RT_TILE_ORDER_ASCENDING and sc.tile_order() is None
+    first, mode = shard(1)
+    assert mode == rt.RT_TILE_ORDER_LEARNING and np.array_equal(first, plain)
+    order, cost = sc.tile_order()
+    assert len(order) == n and np.array_equal(np.sort(order), np.arange(n))
+    along = cost[order].astype(np.int64)
+    assert np.all(np.diff(along) <= 0) and along[0] > along[-1]  # deepest first; book-one has sky tiles and glass tiles
+    # ties keep the ascending order
+    same = np.diff(along) == 0
+    assert np.all(np.diff(order.astype(np.int64))[same] > 0)
+    # the costs are the path lengths: scatter events of every sample of the shard (one per segment but the last)
+    _, cnt = sc.render(cam, W, H, spp, depth, seed=1, counters=True, shard=(1, world))
+    assert 0 <= cnt["segments"] - int(cost.sum()) <= cnt["samples"]
+    for flags in (0, rt.RT_FLAG_DEFERRED_OUTPUT):
+        again, mode = shard(1, flags)
+        assert mode == rt.RT_TILE_ORDER_LEARNT and np.array_equal(again, plain)
+    other_seed, mode = shard(1, seed=2)  # the order belongs to the view, not to the samples
+    assert mode == rt.RT_TILE_ORDER_LEARNT and not np.array_equal(other_seed, plain)
+    plain2, _ = shard(2, rt.RT_FLAG_ASCENDING_TILES)
+    other, mode = shard(2)  # another shard is another view: learnt anew
+    assert mode == rt.RT_TILE_ORDER_LEARNING and np.array_equal(other, plain2)
+    back, mode = shard(1)
+    assert mode == rt.RT_TILE_ORDER_LEARNING and np.array_equal(back, plain)
+    # a whole image is rendered in ascending order
+    whole = torch.zeros(rt.shard_tile_count(W, H, 0, 1) * 64 * 3, dtype=torch.float64, device=dev)
+    sc.render_tiles_device(cam, W, H, spp, depth, 1, (0, 1), whole.data_ptr(), None, stream.cuda_stream)
+    assert sc.last_launch_config()["tile_order"] == rt.RT_TILE_ORDER_ASCENDING
+    torch.cuda.synchronize()
+    sc.status()
+
+
 def test_sweep_scene_78971_on_the_gpu(rt, scenes, oracle, gpu_device):
     """the scene of the 60 000-scene sweep whose 35-bounce path inside a scaled medium lost the medium at |d| = 1e-38"""
     from test_random_scenes import random_scene_r3
