@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path on a box with fewer GPUs (shards staged through host memory)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--collective-at-one", action="store_true",
+                    help="rehearsal on a one-GPU box: with ONE rank, still bring the communicator up (RCCL for --backend nccl) and send "
+                         "the tiles through dist.gather, as the N > 1 path does")
     ap.add_argument("--check", action="store_true", help="rank 0 also renders the whole image alone and compares (default for N > 1)")
     ap.add_argument("--no-check", action="store_true", help="skip that comparison for N > 1")
     ap.add_argument("--ascending-tiles", action="store_true",
@@ -217,10 +220,11 @@ def rank_environment():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
-def predicted_strong_scaling(n):
-    """profiles / tools/shard_scaling.py: speed-up over N = 1 predicted from per-shard kernel times measured on ONE MI355X (1/N
-    shard of the image, before the gather): a prediction printed beside the measurement, never instead of it"""
-    return {1: 1.0, 2: 1.97, 4: 3.81, 8: 7.09}.get(n)
+def predicted_strong_scaling(n, ascending=False):
+    """profiles/r04_shard_scaling*.log (tools/shard_scaling.py): speed-up over N = 1 predicted from per-shard times measured on ONE
+    MI355X (1/N shard of the image, render + sums, before the gather), in the learnt tile order or in ascending order: a prediction
+    printed beside the measurement, never instead of it"""
+    return ({1: 1.0, 2: 1.96, 4: 3.80, 8: 7.09} if ascending else {1: 1.0, 2: 1.97, 4: 3.86, 8: 7.23}).get(n)
 
 
 def main():
@@ -241,7 +245,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    collective = world > 1 or a.collective_at_one
+    if collective:
+        if "MASTER_PORT" not in os.environ:  # (only without a launcher: --collective-at-one)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         # the communicator comes up -- and is exercised once -- BEFORE any render, so that an RCCL failure cannot be
         # mistaken for a kernel failure (and the other way round)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -325,10 +335,10 @@ def main():
                 mark("start", rs)
                 sc.render_tiles_device(cam, W, H, spp, depth, a.seed, (rank, world), mine_k.data_ptr(), None, stream, flags=order_flag)
                 mark("render", rs)
-            if world > 1 and a.backend == "nccl":
+            if collective and a.backend == "nccl":
                 glist = list(gathered_k.chunk(world)) if rank == 0 else None
                 dist.gather(mine_k, glist, dst=0)  # the one collective of the path (RCCL over xGMI)
-            elif world > 1:
+            elif collective:
                 hm = mine_k.cpu()
                 hl = [torch.zeros_like(hm) for _ in range(world)] if rank == 0 else None
                 dist.gather(hm, hl, dst=0)
@@ -337,7 +347,7 @@ def main():
             mark("gather", rs)
             if rank == 0:
                 b = k & 1
-                src = gathered_k if world > 1 else mine_k
+                src = gathered_k if collective else mine_k
                 rs.wait_event(copy_done[b])  # the copy that last read images[b] has finished
                 rt.unpack_tiles_device(src.data_ptr(), pad_tiles, world, W, H, images[b].data_ptr(), stream)
                 mark("unpack", rs)
@@ -352,7 +362,7 @@ def main():
                 post_done[k % 2].record(rs)
 
     def sync():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -396,7 +406,7 @@ def main():
 
     tmax = torch.tensor([dt, kernel_avg_ms, single_render_ms], dtype=torch.float64, device=dev)
     per_rank = None
-    if world > 1:
+    if collective:
         if a.backend == "gloo":
             tmax = tmax.cpu()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -448,6 +458,7 @@ def main():
             "config": {"workload": f"{scene_words} {W}x{H}, {spp} spp, depth {depth}" + (f" (BASELINE.json {cfg_name})" if cfg_name else ""),
                        "scene_seed": a.scene_seed, "render_seed": a.seed, "n_prims": info["n_prims"],
                        "bvh_nodes": info["n_nodes"], "sharding": f"8x8 tiles, tile_id % {world}, one RCCL gather",
+                       "collective": (f"dist.gather over {a.backend}" + (" (RCCL)" if a.backend == "nccl" else "") + f", {world} rank(s)") if collective else None,
                        "library": rt.version(), "steps_pipelined_on_two_streams": bool(a.pipeline),
                        "sums_behind_the_next_render": bool(defer),
                        "tile_order": {0: "ascending" + (" (a whole image always is)" if world == 1 else ""),
@@ -461,7 +472,7 @@ def main():
             "step_anatomy_ms": per_rank if per_rank is not None else [dict(anatomy, rank=0, device=local_rank, tiles=n_tiles[0])],
         }
         image_ok = True
-        if (world > 1 and not a.no_check) or a.check:
+        if (collective and not a.no_check) or a.check:
             whole = sc.render(cam, W, H, spp, depth, a.seed)
             last = host_images[(step_no[0] - 1) & 1]
             image_ok = bool(np.array_equal(last.numpy().reshape(H, W, 3), whole))
@@ -472,7 +483,7 @@ def main():
             res["ranks"] = {"render_ms": {"min": min(rms), "max": max(rms), "mean": sum(rms) / len(rms), "spread": max(rms) - min(rms)},
                             "gather_ms_rank0": per_rank[0].get("gather_ms"), "unpack_ms_rank0": per_rank[0].get("unpack_ms"),
                             "d2h_ms_rank0": per_rank[0].get("d2h_ms"),
-                            "predicted_speedup_over_1_gpu": predicted_strong_scaling(world),
+                            "predicted_speedup_over_1_gpu": predicted_strong_scaling(world, a.ascending_tiles),
                             "prediction_source": "tools/shard_scaling.py: per-shard kernel times on one MI355X, before the gather"}
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(desc, scene_words, W, H, spp, depth, a.seed, a.cpu_seconds, scenes)
@@ -481,7 +492,7 @@ def main():
         print(json.dumps(res), flush=True)
     else:
         image_ok = True
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
     if not image_ok:  # the line above says so; the exit code does too (the launcher relays it)

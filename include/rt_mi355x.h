@@ -262,7 +262,8 @@ typedef struct rt_launch_config {
 int rt_last_launch_config(rt_scene *, rt_launch_config *out);
 /* A render of a SHARD (shard_count > 1) hands its tiles to the waves deepest first: the few 100-segment paths that finish a launch
  * alone (a fixed ~1 ms, 12 % of a 1/8 shard of book-one) then start early and the launch ends on shallow tiles.  The order is learnt:
- * the first render of a view (camera, size, shard, depth) adds up the path lengths per tile beside its sums and sorts the tiles; later
+ * the first render of a view (camera, size, shard, depth) adds up the path lengths per tile beside its sums and sorts the tiles (in eight
+ * steps of depth, ascending within a step); later
  * renders of the same view use that order as soon as it is complete (never waiting for it).  The image does not depend on the order
  * (the reference deals rows to threads in no particular order either, examples/book-one.rs:56-65).  A whole image (shard_count 1)
  * is always rendered in ascending order (neighbouring tiles share rays: faster there). */

@@ -378,6 +378,7 @@ static int check_device_status(rt_scene::RenderSlot &sl) {
     return fail(RT_ERR_DEVICE, "device error word " + std::to_string(st) + ":" + what + " the image is incomplete");
 }
 
+#define RT_TILE_ORDER_LEVELS 8
 // what a learnt tile order belongs to: the view (never 0)
 static uint64_t view_key(const rt_camera *cam, const rt_render_params *p) {
     uint64_t h = 0xCBF29CE484222325ull;
@@ -512,7 +513,10 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     int order_mode = RT_TILE_ORDER_ASCENDING;
     uint64_t order_key = 0;
     rt_scene::TileOrder &to = s->tile_order;
-    int order_levels = 0;
+    // costs are compared in eight steps of the largest one: tiles of about the same depth keep their ascending order, in which
+    // neighbouring tiles share the rays' neighbourhoods (the exact order costs a LONG launch more than its end gains: a 1/8 shard of
+    // 3840x2160x2000 266 -> 271 ms, in eight steps 266 -> 266; the short shards gain the same either way, docs/experiments.md 1.4)
+    int order_levels = RT_TILE_ORDER_LEVELS;
     bool order_whole = false;
 #if defined(RT_TEST_HOOKS) // experiments (tools/tile_order_probe.py)
     if (const char *t = std::getenv("RT_TEST_TILE_ORDER_LEVELS")) order_levels = std::atoi(t);

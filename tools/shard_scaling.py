@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Run on the GPU box (1 GPU): time one shard of the headline workload for N = 1, 2, 4, 8 -- the per-GPU work of a
-strong-scaling run without the gather -- to predict the driver's multi-GPU scaling."""
+strong-scaling run without the gather -- to predict the driver's multi-GPU scaling.  The first render of a shard learns its tile
+order, the timed ones use it (`--ascending`: the ascending order, as before round 4)."""
 import importlib
 import sys
 import time
@@ -17,6 +18,7 @@ scenes = importlib.import_module("ray_tracer_amd.scenes")
 W, H, spp, depth = 1200, 800, 500, 100
 sc, cam = scenes.build_product(scenes.book_one(1, W / H), device=0)
 dev = torch.device("cuda", 0)
+flags = rt.RT_FLAG_ASCENDING_TILES if "--ascending" in sys.argv else 0
 base = None
 for n in (1, 2, 4, 8):
     worst, worst_kern, kern = 0.0, 0.0, 0.0
@@ -28,7 +30,7 @@ for n in (1, 2, 4, 8):
         for _ in range(4):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            sc.render_tiles_device(cam, W, H, spp, depth, 1, (r, n), buf.data_ptr(), None, st)
+            sc.render_tiles_device(cam, W, H, spp, depth, 1, (r, n), buf.data_ptr(), None, st, flags=flags)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             if dt < best:

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=8)
     ap.add_argument("--out", default="gpurun_out/tile_order_probe.json")
     ap.add_argument("--scenes", default="book_one,cornell,cover")
+    ap.add_argument("--size", default="", help="W,H,spp instead of the scene's BASELINE size")
     ap.add_argument("--worlds", default="2,4,8", help="shard counts; 1 (a whole image) needs the test-hooks library and RT_TEST_TILE_ORDER_WHOLE=1")
     a = ap.parse_args()
     import torch
@@ -31,7 +32,7 @@ def main():
     sizes = {"book_one": (1200, 800, 500), "cornell": (600, 600, 1000), "cover": (800, 800, 1000)}
     rows = []
     for name in a.scenes.split(","):
-        W, H, spp = sizes[name]
+        W, H, spp = [int(v) for v in a.size.split(",")] if a.size else sizes[name]
         desc = {"book_one": lambda: scenes.book_one(1, W / H), "cornell": scenes.cornell, "cover": lambda: scenes.cover(1)}[name]()
         sc, cam = scenes.build_product(desc, device=0)
         for world in [int(w) for w in a.worlds.split(",")]:
