@@ -875,6 +875,8 @@ def test_a_shard_learns_its_tile_order_and_the_image_does_not_change(rt, scenes,
     assert mode == rt.RT_TILE_ORDER_LEARNING and np.array_equal(first, plain)
     order, cost = sc.tile_order()
     assert len(order) == n and np.array_equal(np.sort(order), np.arange(n))
+    with pytest.raises(rt.RtError):  # a buffer smaller than the table is an error, not an overrun
+        sc.tile_order(capacity=n - 1)
     # deepest first, the costs compared in eight steps of the largest one (rt_api.cpp RT_TILE_ORDER_LEVELS); within a step ascending
     level = (cost // (cost.max() // np.uint64(8) + np.uint64(1))).astype(np.int64)
     along = level[order]
