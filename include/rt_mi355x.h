@@ -246,7 +246,7 @@ int rt_last_kernel_ms(rt_scene *, float *ms);
 /* how the last render on this scene was launched (diagnostics; the figures rocprofv3 prints for VGPRs / LDS of a
  * dispatch are not reliable for these kernels): persistent workgroups, threads per workgroup, dynamic LDS per
  * workgroup, resident workgroups per CU, CUs, passes over the sample workspace, jobs of the last pass and their size,
- * kernel family feature bits (1 general prims, 2 media, 4 textures), whether the node array is in LDS and the
+ * kernel family feature bits (1 general prims, 2 media, 4 textures), whether the node array (and, for small general scenes, every record) is in LDS and the
  * swap-at-shade queues are in use (and their capacity), and the bytes of per-sample workspace the render used */
 typedef struct rt_launch_config {
     int blocks, block_threads;
@@ -258,6 +258,7 @@ typedef struct rt_launch_config {
     size_t workspace_bytes;
     int swap_cap, waves_per_simd; /* entries per swap queue; waves per SIMD the kernel family is compiled for */
     int tile_order;               /* RT_TILE_ORDER_* */
+    int records_in_lds;           /* 1: a small general scene (box-list walk) whose transform / prim / material records the kernel keeps in LDS */
 } rt_launch_config;
 int rt_last_launch_config(rt_scene *, rt_launch_config *out);
 /* A render of a SHARD (shard_count > 1) hands its tiles to the waves deepest first: the few 100-segment paths that finish a launch

@@ -78,7 +78,7 @@ class rt_launch_config(C.Structure):
     _fields_ = [("blocks", C.c_int), ("block_threads", C.c_int), ("lds_bytes", C.c_uint), ("blocks_per_cu", C.c_int),
                 ("n_cu", C.c_int), ("passes", C.c_int), ("n_jobs", C.c_int), ("job_spp", C.c_int),
                 ("kernel_features", C.c_uint), ("lds_nodes", C.c_int), ("swap", C.c_int), ("workspace_bytes", C.c_size_t),
-                ("swap_cap", C.c_int), ("waves_per_simd", C.c_int), ("tile_order", C.c_int)]
+                ("swap_cap", C.c_int), ("waves_per_simd", C.c_int), ("tile_order", C.c_int), ("records_in_lds", C.c_int)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -256,6 +256,7 @@ int rt_scene_commit(rt_scene *s, int device) {
         if ((rc = upload(s->flat.materials, &s->d_materials, &total))) return rc;
         if ((rc = upload(s->flat.textures, &s->d_textures, &total))) return rc;
         if ((rc = upload(s->flat.image_blob, &s->d_blob, &total))) return rc;
+        if ((rc = upload(s->flat.scene_blob, &s->d_scene_blob, &total))) return rc; // list mode: the records the kernels keep in LDS
         s->device_bytes = total;
     }
     s->committed = true;
@@ -307,6 +308,7 @@ static void fill_launch(const rt_scene *s, const rt_camera *cam, const rt_render
     L->prim_extra = (const RtPrimExtra *)s->d_prim_extra;
     L->xforms = s->d_xforms ? (const RtXform *)((const unsigned char *)s->d_xforms + s->flat.xform_store_offset()) : nullptr;
     L->materials = (const RtMaterial *)s->d_materials;
+    L->xforms_global = L->xforms;
     L->textures = (const RtTexture *)s->d_textures;
     L->image_blob = (const uint8_t *)s->d_blob;
     L->n_nodes = (int)s->flat.nodes.size();
@@ -462,8 +464,25 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     const unsigned groups_per_cu = std::max(1u, (unsigned)rt_kernel_waves_per_simd(feat) * 256u / block);
     const unsigned lds_share = (RT_LDS_PER_CU / groups_per_cu) & ~(RT_LDS_GRANULE - 1u);
     const int list = s->flat.n_list > 0; // the box list (< 1 KB) always lives in LDS
-    const unsigned front = rt_lds_front_bytes((feat & ~1u) != 0u); // the families with media / textures keep the log table there
     const unsigned min_cap = swap ? (block >= 512u ? (unsigned)RT_SWAP_CAP : 32u) : 0u; // the node copy must leave room for this
+    // the families with media / textures keep the log table at the front; a LIST scene's records follow it when they fit the
+    // workgroup's share beside the stack, the box list and the smallest queues (rtl::rec_at<true>: Cornell box 138 -> 126 ms)
+    const unsigned table = rt_lds_front_bytes((feat & ~1u) != 0u);
+    const unsigned blob_bytes = (unsigned)s->flat.scene_blob.size();
+    const int reclds = list && swap && blob_bytes > 0u &&
+                       rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, node_bytes, min_cap, table + rt_lds_scene_room(blob_bytes)).total <= lds_share;
+    const unsigned front = table + (reclds ? rt_lds_scene_room(blob_bytes) : 0u);
+    if (reclds) { // these five fields carry the arrays' byte offsets in the LDS instead of addresses
+        const uint32_t *off = s->flat.scene_blob_off;
+        L.scene_blob = (const unsigned char *)s->d_scene_blob;
+        L.scene_bytes = blob_bytes;
+        L.scene_lds_off = table;
+        if (RT_LIST_LDS_ARRAYS & 1) L.xforms = (const RtXform *)(uintptr_t)(table + off[0]);
+        if (RT_LIST_LDS_ARRAYS & 2) L.prim_geo = (const RtPrimGeo *)(uintptr_t)(table + off[1]);
+        if (RT_LIST_LDS_ARRAYS & 4) L.prim_meta = (const RtPrimMeta *)(uintptr_t)(table + off[2]);
+        if (RT_LIST_LDS_ARRAYS & 8) L.prim_extra = (const RtPrimExtra *)(uintptr_t)(table + off[3]);
+        if (RT_LIST_LDS_ARRAYS & 16) L.materials = (const RtMaterial *)(uintptr_t)(table + off[4]);
+    }
     const int ldsnodes = list || (!wide && node_bytes > 0 && !(no_lds && *no_lds == '1') &&
                                   rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, node_bytes, min_cap, front).total <= lds_share);
     const unsigned in_lds = ldsnodes ? node_bytes : 0u;
@@ -478,7 +497,7 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     if (const char *t = std::getenv("RT_TEST_LDS_SHORT")) // claim fewer bytes than the layout needs -> the kernel must refuse
         if (*t == '1') L.lds_bytes = lds_bytes - 64u;
 #endif
-    const int lds_mode = (ldsnodes ? 1 : 0) | (swap ? 2 : 0) | (wide ? 4 : 0) | (list ? 8 : 0);
+    const int lds_mode = (ldsnodes ? 1 : 0) | (swap ? 2 : 0) | (wide ? 4 : 0) | (list ? 8 : 0) | (reclds ? 16 : 0);
     int per_cu = 0, n_cu = 0, rc = 0;
     const unsigned occ_key = feat | (lens ? 32u : 0u) | (count ? 64u : 0u) | ((unsigned)lds_mode << 7); // feat uses bits 0-4
     if (s->occ_key == occ_key && s->occ_lds == lds_bytes) {
@@ -637,6 +656,7 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     lc.swap_cap = (int)swap_cap;
     lc.waves_per_simd = rt_kernel_waves_per_simd(feat);
     lc.tile_order = order_mode;
+    lc.records_in_lds = reclds;
     return RT_OK;
 }
 

@@ -996,6 +996,20 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
         std::memcpy(fs.xform_store.data() + fs.xforms.size() * (sizeof(RtXformBox) / sizeof(double)) + i * (sizeof(RtXform) / sizeof(double)), &fs.xforms[i],
                     sizeof(RtXform));
     }
+    // the records the LIST kernels copy into LDS when they fit beside the stack and the queues (rt_api.cpp render_range decides per
+    // launch), in the layout RtLaunch's offsets assume
+    if (fs.n_list > 0 && FlatScene::scene_blob_bytes(fs.xforms.size(), fs.prim_meta.size(), fs.materials.size()) <= (size_t)RT_LIST_SCENE_MAX) {
+        auto put = [&](int k, const void *src, size_t bytes) {
+            fs.scene_blob_off[k] = (uint32_t)fs.scene_blob.size();
+            fs.scene_blob.resize(fs.scene_blob.size() + ((bytes + 15) & ~(size_t)15), 0);
+            if (bytes) std::memcpy(fs.scene_blob.data() + fs.scene_blob_off[k], src, bytes);
+        };
+        put(0, fs.xforms.data(), fs.xforms.size() * sizeof(RtXform));
+        put(1, fs.prim_geo.data(), fs.prim_geo.size() * sizeof(RtPrimGeo));
+        put(2, fs.prim_meta.data(), fs.prim_meta.size() * sizeof(RtPrimMeta));
+        put(3, fs.prim_extra.data(), fs.prim_extra.size() * sizeof(RtPrimExtra));
+        put(4, fs.materials.data(), fs.materials.size() * sizeof(RtMaterial));
+    }
     *out = std::move(fs);
     return RT_OK;
 }

@@ -265,9 +265,12 @@ __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__bui
 extern __shared__ __attribute__((aligned(16))) unsigned char rt_lds[];
 
 // LIST: the scene's leaves are a box list in LDS instead of a tree (small general scenes, rtl::trav_list_step)
-template <bool GENERAL, int MEDIUM, bool TEXTURED, bool LENS, bool COUNT, bool LDSNODES, bool SWAP, bool WIDE, bool LIST>
+template <bool GENERAL, int MEDIUM, bool TEXTURED, bool LENS, bool COUNT, bool LDSNODES, bool SWAP, bool WIDE, bool LIST, bool RECLDS>
 __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM)) void render_kernel(const RtLaunch L) {
     constexpr int kBlock = block_of(GENERAL, MEDIUM);
+    // the lane program's GENERAL: 0 spheres only, 1 general prims with their records in global memory, 2 (RECLDS: box-LIST scenes
+    // whose records fit) with the records in this workgroup's LDS (rt_lane.h rec_at<true>)
+    constexpr int G = GENERAL ? (RECLDS ? 2 : 1) : 0;
     typedef typename StackOf<kBlock, WIDE>::type Stack;
     typedef typename Stack::Ref Ref;
     // entries per class queue: the most (<= RT_SWAP_CAP) that leaves the kernel family's full occupancy resident (host)
@@ -280,11 +283,13 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
     const uint32_t node_lds_bytes = LDSNODES ? (uint32_t)L.n_nodes * (uint32_t)sizeof(RtNode) : 0u;
     // ONE layout function for host and device (rt_lds.h); a launch that provides fewer bytes than it needs is refused
     // instead of run: every wave returns at once and the host reports RT_ERR_DEVICE
+    constexpr uint32_t kTableBytes = rt_lds_front_bytes(MEDIUM != 0 || TEXTURED);
     const RtLdsLayout lay = rt_lds_layout((uint32_t)L.stack_entries, (uint32_t)kBlock, kStackEntry, node_lds_bytes, kSwapCap,
-                                          rt_lds_front_bytes(MEDIUM != 0 || TEXTURED));
+                                          kTableBytes + (G == 2 ? rt_lds_scene_room(L.scene_bytes) : 0u));
     st.set(rt_lds + lay.stack_off);
     const uint32_t kSwapClassBytes = lay.swap_class_bytes;
-    if (lay.total > L.lds_bytes) { // wave-uniform (kernel arguments only)
+    // (the host's record offsets assume the records start right behind the family's table)
+    if (lay.total > L.lds_bytes || (G == 2 && L.scene_lds_off != kTableBytes)) { // wave-uniform (kernel arguments only)
         if (threadIdx.x == 0u) atomicOr(L.status, RT_DEV_ERR_LDS_LAYOUT);
         return;
     }
@@ -299,6 +304,11 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
     if (SWAP && threadIdx.x < RT_SWAP_HDR_BYTES / 4u) swap_hdr[threadIdx.x] = 0u;
     if (MEDIUM != 0 || TEXTURED) // the log table (rt_libm.h) at the front of the workgroup's LDS: rtl::log_cold reads it there
         for (uint32_t i = threadIdx.x; i < RT_LDS_LOG_TABLE_BYTES / 8u; i += (uint32_t)kBlock) reinterpret_cast<double *>(rt_lds)[i] = rtm_log_tab[i];
+    if (G == 2) { // the scene's records (transforms, prims, materials), packed by the host in the layout the offsets in L assume
+        uint4 *dst = reinterpret_cast<uint4 *>(rt_lds + kTableBytes);
+        const uint4 *src = reinterpret_cast<const uint4 *>(L.scene_blob);
+        for (uint32_t i = threadIdx.x; i < L.scene_bytes / 16u; i += (uint32_t)kBlock) dst[i] = src[i];
+    }
     if (LDSNODES) {
         uint4 *dst = reinterpret_cast<uint4 *>(rt_lds + lay.node_off);
         const uint4 *src = reinterpret_cast<const uint4 *>(L.nodes);
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                 if (is_done && has_path) {
                     uint32_t mat = RT_NO_MATERIAL, kind = RT_MAT_KIND_NONE;
                     if (tv.best_prim != 0xFFFFFFFFu) { // one 8-byte load: the material's kind rides in the meta word
-                        const uint2 pm = *reinterpret_cast<const uint2 *>((GENERAL || MEDIUM) ? &rtl::rec_at(L.prim_meta, tv.best_prim) : &L.prim_meta[tv.best_prim]);
+                        const uint2 pm = *reinterpret_cast<const uint2 *>((GENERAL || MEDIUM) ? &rtl::rec_at<G == 2>(L.prim_meta, tv.best_prim) : &L.prim_meta[tv.best_prim]);
                         kind = (pm.x >> 8) & 0xFFu;
                         mat = pm.y;
                     }
@@ -384,7 +394,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                         cls = kInPlace;
                     } else {
                         rtl::V3 rad = rtl::mk(0.0, 0.0, 0.0);
-                        if (kind == RT_MAT_DIFFUSE_LIGHT) rad = ps.T * rtl::ld3(((GENERAL || MEDIUM) ? rtl::rec_at(L.materials, mat) : L.materials[mat]).rgb); // finish_segment's T * emit
+                        if (kind == RT_MAT_DIFFUSE_LIGHT) rad = ps.T * rtl::ld3(((GENERAL || MEDIUM) ? rtl::rec_at<G == 2>(L.materials, mat) : L.materials[mat]).rgb); // finish_segment's T * emit
                         store_sample(L.samples, slot, rad, ps.k);
                         has_path = false;
                         cls = kEmpty;
@@ -560,7 +570,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                 }
                 if (has_path && cls <= kInPlace) {
                     rtl::V3 rad;
-                    const bool fin = rtl::finish_segment<GENERAL, MEDIUM, TEXTURED>(L, &ps, tv, &rad, RT_BALL_ITERS, &pending);
+                    const bool fin = rtl::finish_segment<G, MEDIUM, TEXTURED>(L, &ps, tv, &rad, RT_BALL_ITERS, &pending);
                     if (COUNT && !pending) {
                         ++c_segs;
                         ++w_scat;
@@ -581,7 +591,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
             } else if (is_done) {
                 if (has_path) {
                     rtl::V3 rad;
-                    const bool fin = rtl::finish_segment<GENERAL, MEDIUM, TEXTURED>(L, &ps, tv, &rad, RT_BALL_ITERS, &pending);
+                    const bool fin = rtl::finish_segment<G, MEDIUM, TEXTURED>(L, &ps, tv, &rad, RT_BALL_ITERS, &pending);
                     if (COUNT && !pending) ++c_segs;
                     if (fin) {
                         // one 32-byte aligned record per sample, two 16-byte stores: whole sectors,
@@ -686,7 +696,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
             t_ref += t0 - t1;
             if (part && !pending) {
                 if (has_path)
-                    rtl::begin_segment<GENERAL, MEDIUM, TEXTURED>(L, &ps, tv, st, &c_prims);
+                    rtl::begin_segment<G, MEDIUM, TEXTURED>(L, &ps, tv, st, &c_prims);
                 else // SWAP: an empty lane waits (DONE, no path) for a parked path or the next bulk refill
                     tv.cur = (!SWAP || queue_empty) ? Ref::kDead : Ref::kDone;
             }
@@ -700,7 +710,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
                 c_ll += (unsigned long long)nL;
             }
             RT_STAMP(t0);
-            if (is_leaf) rtl::leaf_step<GENERAL, MEDIUM, TEXTURED>(L, &ps, tv, st, &c_prims);
+            if (is_leaf) rtl::leaf_step<G, MEDIUM, TEXTURED>(L, &ps, tv, st, &c_prims);
             RT_STAMP(t1);
             t_l += t1 - t0;
         } else {
@@ -906,9 +916,9 @@ __global__ void probe_libm_kernel(int which, const double *a, const double *b, i
 // ---- dispatch over the template instantiations ----
 typedef void (*KernelFn)(const RtLaunch);
 
-template <bool GENERAL, int MEDIUM, bool TEXTURED, bool SWAP, bool WIDE = false, bool LIST = false>
+template <bool GENERAL, int MEDIUM, bool TEXTURED, bool SWAP, bool WIDE = false, bool LIST = false, bool RECLDS = false>
 KernelFn pick3(bool lens, bool count, bool ldsnodes) {
-#define RT_PICK(LN, C, LD) return render_kernel<GENERAL, MEDIUM, TEXTURED, LN, C, (LD && !WIDE) || LIST, SWAP, WIDE, LIST>
+#define RT_PICK(LN, C, LD) return render_kernel<GENERAL, MEDIUM, TEXTURED, LN, C, (LD && !WIDE) || LIST, SWAP, WIDE, LIST, RECLDS>
     if (lens) {
         if (count) {
             if (ldsnodes) RT_PICK(true, true, true); else RT_PICK(true, true, false);
@@ -925,7 +935,8 @@ KernelFn pick3(bool lens, bool count, bool ldsnodes) {
 #undef RT_PICK
 }
 // lds_mode: bit 0 = node array copied to LDS, bit 1 = swap-at-shade queues, bit 2 = 32-bit references (general families),
-// bit 3 = box list instead of the tree (general families, 16-bit references, always in LDS)
+// bit 3 = box list instead of the tree (general families, 16-bit references, always in LDS), bit 4 = (list + swap only) the scene's
+// records in LDS
 #if RT_TU_PART == 0 || RT_TU_PART == 3
 // media inside the boundary of media (feature bit 16): MEDIUM = 3, the only family compiled with the nested evaluation (a real
 // call per inner medium, records in scratch memory: 6 x slower than MEDIUM = 2 on the same scene, so it is kept out of it).
@@ -940,6 +951,8 @@ KernelFn pick_nested(bool lens, bool count, int lds_mode) {
 // the families with media / textures (feature bits 2, 4, 8)
 KernelFn pick_media(unsigned features, bool lens, bool count, int lds_mode) {
     const bool ldsnodes = (lds_mode & 1) != 0, swap = (lds_mode & 2) != 0, wide = (lds_mode & 4) != 0, list = (lds_mode & 8) != 0;
+    if (list && swap && (lds_mode & 16) != 0)
+        return (features & 8u) ? pick3<true, 2, true, true, false, true, true>(lens, count, true) : pick3<true, 1, true, true, false, true, true>(lens, count, true);
     if (list) {
         if (features & 8u) return swap ? pick3<true, 2, true, true, false, true>(lens, count, true) : pick3<true, 2, true, false, false, true>(lens, count, true);
         return swap ? pick3<true, 1, true, true, false, true>(lens, count, true) : pick3<true, 1, true, false, false, true>(lens, count, true);
@@ -983,6 +996,7 @@ KernelFn pick(unsigned features, bool lens, bool count, int lds_mode) {
 #endif
     }
     // general prims only (matrices, rectangles, cubes: the Cornell box): no medium / texture code in the kernel
+    if (list && swap && (lds_mode & 16) != 0) return pick3<true, 0, false, true, false, true, true>(lens, count, true);
     if (list) return swap ? pick3<true, 0, false, true, false, true>(lens, count, true) : pick3<true, 0, false, false, false, true>(lens, count, true);
     if (wide) return swap ? pick3<true, 0, false, true, true>(lens, count, false) : pick3<true, 0, false, false, true>(lens, count, false);
     if (features == 1u) return swap ? pick3<true, 0, false, true>(lens, count, ldsnodes) : pick3<true, 0, false, false>(lens, count, ldsnodes);

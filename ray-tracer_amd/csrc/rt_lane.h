@@ -147,8 +147,29 @@ template <class T>
 RT_HD uint32_t rec_off(uint32_t i) { // byte offset of record i: a shift for the power-of-two records, one v_mul_u32_u24 for the others
     return (sizeof(T) & (sizeof(T) - 1)) == 0 ? i * (uint32_t)sizeof(T) : mul24(i, (uint32_t)sizeof(T));
 }
-template <class T>
+// LDS = true (kernels of the box-LIST mode, GENERAL == 2): the scene's records live in the workgroup's LDS (copied there at kernel
+// entry, rt_kernels.hip) and `base` is not a pointer but the array's byte offset in the LDS, which the host put into the launch
+// descriptor's pointer field (rt_api.cpp fill_launch): a small general scene reads a transform level (96-192 bytes) per primitive
+// test, and those loads -- L1 hits all of them -- kept the texture-address path as busy as the VALUs (Cornell box 138 -> 126 ms).
+#if defined(__HIP_DEVICE_COMPILE__)
+extern __shared__ __attribute__((aligned(16))) unsigned char rt_lds[];
+#endif
+template <class T> struct RecLdsBit { static constexpr unsigned value = 0u; };
+template <> struct RecLdsBit<RtXform> { static constexpr unsigned value = 1u; };
+template <> struct RecLdsBit<RtPrimGeo> { static constexpr unsigned value = 2u; };
+template <> struct RecLdsBit<RtPrimMeta> { static constexpr unsigned value = 4u; };
+template <> struct RecLdsBit<RtPrimExtra> { static constexpr unsigned value = 8u; };
+template <> struct RecLdsBit<RtMaterial> { static constexpr unsigned value = 16u; };
+template <bool LDS = false, class T>
 RT_HD const T &rec_at(const T *base, uint32_t i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (LDS && (RecLdsBit<T>::value & (unsigned)RT_LIST_LDS_ARRAYS) != 0u) {
+        // (the offsets are multiples of 16 -- rt_host.cpp packs the arrays that way -- and saying so here is what lets the compiler
+        // read a record with ds_read_b128 instead of pairs of 64-bit reads)
+        const uint32_t at = ((uint32_t)reinterpret_cast<uintptr_t>(base) & ~15u) + rec_off<T>(i);
+        return *reinterpret_cast<const T *>(__builtin_assume_aligned(rt_lds + at, 16));
+    }
+#endif
     return *reinterpret_cast<const T *>(reinterpret_cast<const unsigned char *>(base) + rec_off<T>(i));
 }
 
@@ -491,14 +512,14 @@ struct SegCtx { // what a primitive test may need besides the ray
 // M^-1 (o,1) = o + inv_t, M^-1 (d,0) = d, M (p,1) = p + t, M (n,0) = n -- the values the 4x4 products give for it.
 // (constant trip counts: the compiler unrolls them, and a level the wave does not have is one skipped branch; a
 // data-dependent loop here made it keep the hit record in scratch memory)
-template <bool DEEP = false>
+template <bool DEEP = false, bool LDSREC = false>
 RT_HD void chain_down(const RtLaunch &L, uint32_t first, uint32_t len, uint32_t tmask, V3 *o, V3 *d) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (uint32_t i = 0; i < (uint32_t)RT_MAX_CHAIN; ++i) {
         if (i >= len) continue;
-        const RtXform &X = rec_at(L.xforms, first + i);
+        const RtXform &X = rec_at<LDSREC>(L.xforms, first + i);
         if ((tmask >> i) & 1u) {
             *o = mk(o->x + X.inv[3], o->y + X.inv[7], o->z + X.inv[11]);
         } else {
@@ -511,23 +532,23 @@ RT_HD void chain_down(const RtLaunch &L, uint32_t first, uint32_t len, uint32_t 
     // always the full 4x4 products, the reference's own form (src/sprite.rs:101-106)
     if (DEEP)
         for (uint32_t i = (uint32_t)RT_MAX_CHAIN; i < len; ++i) {
-            const RtXform &X = rec_at(L.xforms, first + i);
+            const RtXform &X = rec_at<LDSREC>(L.xforms, first + i);
             const V3 lo = xf_point(X.inv, *o);
             *d = xf_vector(X.inv, *d);
             *o = lo;
         }
 }
-template <bool DEEP = false>
+template <bool DEEP = false, bool LDSREC = false>
 RT_HD void chain_up(const RtLaunch &L, uint32_t first, uint32_t len, uint32_t tmask, Rec *r) {
     if (DEEP)
-        for (uint32_t i = len; i > (uint32_t)RT_MAX_CHAIN; --i) to_world(rec_at(L.xforms, first + i - 1u), r);
+        for (uint32_t i = len; i > (uint32_t)RT_MAX_CHAIN; --i) to_world(rec_at<LDSREC>(L.xforms, first + i - 1u), r);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (uint32_t k = 0; k < (uint32_t)RT_MAX_CHAIN; ++k) {
         const uint32_t i = (uint32_t)RT_MAX_CHAIN - 1u - k;
         if (i >= len) continue;
-        const RtXform &X = rec_at(L.xforms, first + i);
+        const RtXform &X = rec_at<LDSREC>(L.xforms, first + i);
         if ((tmask >> i) & 1u)
             r->p = mk(r->p.x + X.m[3], r->p.y + X.m[7], r->p.z + X.m[11]);
         else
@@ -535,17 +556,17 @@ RT_HD void chain_up(const RtLaunch &L, uint32_t first, uint32_t len, uint32_t tm
     }
 }
 
-template <bool DEEP = false>
+template <bool DEEP = false, bool LDSREC = false>
 RT_HD void chain_up_point(const RtLaunch &L, uint32_t first, uint32_t len, uint32_t tmask, V3 *p) {
     if (DEEP)
-        for (uint32_t i = len; i > (uint32_t)RT_MAX_CHAIN; --i) *p = xf_point(rec_at(L.xforms, first + i - 1u).m, *p);
+        for (uint32_t i = len; i > (uint32_t)RT_MAX_CHAIN; --i) *p = xf_point(rec_at<LDSREC>(L.xforms, first + i - 1u).m, *p);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (uint32_t k = 0; k < (uint32_t)RT_MAX_CHAIN; ++k) {
         const uint32_t i = (uint32_t)RT_MAX_CHAIN - 1u - k;
         if (i >= len) continue;
-        const RtXform &X = rec_at(L.xforms, first + i);
+        const RtXform &X = rec_at<LDSREC>(L.xforms, first + i);
         if ((tmask >> i) & 1u)
             *p = mk(p->x + X.m[3], p->y + X.m[7], p->z + X.m[11]);
         else
@@ -634,17 +655,17 @@ RT_HD bool shape_hit(uint32_t kind, const RtPrimGeo &G, V3 lo, V3 ld, bool uv, R
 // A boundary prim may itself be a ConstantMedium (T: Hit is generic, src/volume.rs:18-44): it is evaluated -- with a draw of
 // its own, keyed by this evaluation's key and pass (include/rt_rng.h) -- by each of the two boundary.hit calls.  NEST = levels
 // of media that may still follow below this one (the host bounds the nesting to RT_MAX_MEDIUM_NESTING).
-template <int NEST>
+template <int NEST, bool LDSREC>
 RT_HD bool medium_general_hit(const RtLaunch &L, const RtPrimGeo &G, V3 o, V3 d, uint64_t rng_base, uint32_t segment, uint32_t key,
                               unsigned long long *draws, unsigned long long *tests, bool uv, Rec *r);
 // a medium inside a medium's boundary: a real call (rare, and inlining three copies of the evaluation into each other triples the
 // slow kernel family's code)
-template <int NEST>
+template <int NEST, bool LDSREC>
 RT_COLD bool medium_nested_call(const RtLaunch &L, const RtPrimGeo &G, V3 o, V3 d, uint64_t rng_base, uint32_t segment, uint32_t key,
                                 unsigned long long *draws, unsigned long long *tests, bool uv, Rec *r) {
-    return medium_general_hit<NEST>(L, G, o, d, rng_base, segment, key, draws, tests, uv, r);
+    return medium_general_hit<NEST, LDSREC>(L, G, o, d, rng_base, segment, key, draws, tests, uv, r);
 }
-template <int NEST>
+template <int NEST, bool LDSREC>
 RT_HD bool medium_general_hit(const RtLaunch &L, const RtPrimGeo &G, V3 o, V3 d, uint64_t rng_base, uint32_t segment, uint32_t key,
                               unsigned long long *draws, unsigned long long *tests, bool uv, Rec *r) {
     const double density = G.g[0];
@@ -657,27 +678,27 @@ RT_HD bool medium_general_hit(const RtLaunch &L, const RtPrimGeo &G, V3 o, V3 d,
         bool have = false;
         for (uint32_t k = 0; k < count; ++k) {
             const uint32_t ci = first + k;
-            const RtPrimMeta &CM = rec_at(L.prim_meta, ci);
+            const RtPrimMeta &CM = rec_at<LDSREC>(L.prim_meta, ci);
             const uint32_t kw = CM.kind;
             const uint32_t cf = CM.xform, cl = (kw >> RT_META_CHAIN_SHIFT) & 0xFu, cm = (kw >> RT_META_TMASK_SHIFT) & 0xFu;
             V3 co = ro, cd = d;
-            chain_down<true>(L, cf, cl, cm, &co, &cd);
+            chain_down<true, LDSREC>(L, cf, cl, cm, &co, &cd);
             Rec cr;
             ++*tests;
             bool hit;
             if ((kw & 0xFFu) == RT_PRIM_MEDIUM_C) {
                 if constexpr (NEST > 0)
-                    hit = medium_nested_call<NEST - 1>(L, rec_at(L.prim_geo, ci), co, cd, rng_base, segment,
+                    hit = medium_nested_call<NEST - 1, LDSREC>(L, rec_at<LDSREC>(L.prim_geo, ci), co, cd, rng_base, segment,
                                                        rt_medium_key_inner(key, (uint32_t)pass, CM.aux), draws, tests, uv, &cr);
                 else
                     hit = false; // (the host refuses deeper nesting)
             } else {
-                hit = shape_hit<true>(kw & 0xFFu, rec_at(L.prim_geo, ci), co, cd, uv, &cr);
+                hit = shape_hit<true>(kw & 0xFFu, rec_at<LDSREC>(L.prim_geo, ci), co, cd, uv, &cr);
             }
             // (the boundary's own nodes -- a Cube, a node of sprites -- keep boxes too)
-            if (hit && zd && !chain_boxes_admit<true>(L.xforms, cf, cl, cm, ro, d)) hit = false;
+            if (hit && zd && !chain_boxes_admit<true>(L.xforms_global, cf, cl, cm, ro, d)) hit = false;
             if (hit && (!have || cr.t < best.t)) {
-                chain_up<true>(L, cf, cl, cm, &cr);
+                chain_up<true, LDSREC>(L, cf, cl, cm, &cr);
                 best = cr;
                 have = true;
             }
@@ -719,14 +740,14 @@ RT_HD bool medium_general_hit(const RtLaunch &L, const RtPrimGeo &G, V3 o, V3 d,
 // RECORD = false: only r->t is meaningful (traversal); true: full record (shading), uv when `uv`.
 // MEDIUM: 0 no media in the scene, 1 only ConstantMedium<Sphere> sprites under a pure translation (RT_PRIM_MEDIUM_T,
 // the reference's own scenes), 2 media over any boundary (RT_PRIM_MEDIUM_C) as well, 3 media inside the boundary of media too.
-template <bool GENERAL, int MEDIUM, bool RECORD>
+template <int GENERAL, int MEDIUM, bool RECORD>
 RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx &sc, Rec *r, bool uv_wanted) {
     // uv inside the record is only ever asked for by prim_uv's medium case (kernel family MEDIUM = 2)
     const bool uv = MEDIUM >= 2 && uv_wanted;
     // (the spheres-only family keeps the plain indexing: measured 0.9 % faster there, 2.5 % slower on the book-two cover)
-    const RtPrimGeo &G = (GENERAL || MEDIUM) ? rec_at(L.prim_geo, pi) : L.prim_geo[pi];
+    const RtPrimGeo &G = (GENERAL || MEDIUM) ? rec_at<GENERAL == 2>(L.prim_geo, pi) : L.prim_geo[pi];
     uint32_t kw = (uint32_t)RT_PRIM_SPHERE_T;
-    if (GENERAL || MEDIUM) kw = rec_at(L.prim_meta, pi).kind; // bits 8-15 carry the material's kind, 16-23 the chain
+    if (GENERAL || MEDIUM) kw = rec_at<GENERAL == 2>(L.prim_meta, pi).kind; // bits 8-15 carry the material's kind, 16-23 the chain
     const uint32_t kind = kw & 0xFFu;
     ++sc.prims_tested;
     if (kind == RT_PRIM_SPHERE_T) {
@@ -744,23 +765,23 @@ RT_HD bool prim_hit(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double a, SegCtx
         return true;
     }
     if (GENERAL || MEDIUM) {
-        const RtPrimMeta &P = rec_at(L.prim_meta, pi);
+        const RtPrimMeta &P = rec_at<GENERAL == 2>(L.prim_meta, pi);
         if (MEDIUM && kind == RT_PRIM_MEDIUM_T) {
             V3 c = mk(G.g[0], G.g[1], G.g[2]);
-            if (!medium_hit<RECORD>(o - c, d, G.g[3], rec_at(L.prim_extra, pi).e[1], sc.rng_base, sc.segment, P.aux, &sc.draws, uv, r)) return false;
+            if (!medium_hit<RECORD>(o - c, d, G.g[3], rec_at<GENERAL == 2>(L.prim_extra, pi).e[1], sc.rng_base, sc.segment, P.aux, &sc.draws, uv, r)) return false;
             if (RECORD) r->p = r->p + c;
             return true;
         }
         const uint32_t first = P.xform, len = (kw >> RT_META_CHAIN_SHIFT) & 0xFu, tmask = (kw >> RT_META_TMASK_SHIFT) & 0xFu;
         V3 lo = o, ld = d;
-        chain_down<(MEDIUM >= 2)>(L, first, len, tmask, &lo, &ld);
+        chain_down<(MEDIUM >= 2), GENERAL == 2>(L, first, len, tmask, &lo, &ld);
         bool ok;
         if (MEDIUM >= 2 && kind == RT_PRIM_MEDIUM_C)
-            ok = medium_general_hit<(MEDIUM >= 3 ? RT_MAX_MEDIUM_NESTING - 1 : 0)>(L, G, lo, ld, sc.rng_base, sc.segment, P.aux, &sc.draws, &sc.prims_tested, uv, r);
+            ok = medium_general_hit<(MEDIUM >= 3 ? RT_MAX_MEDIUM_NESTING - 1 : 0), GENERAL == 2>(L, G, lo, ld, sc.rng_base, sc.segment, P.aux, &sc.draws, &sc.prims_tested, uv, r);
         else
             ok = shape_hit<RECORD>(kind, G, lo, ld, uv, r);
         if (!ok) return false;
-        if (RECORD) chain_up<(MEDIUM >= 2)>(L, first, len, tmask, r);
+        if (RECORD) chain_up<(MEDIUM >= 2), GENERAL == 2>(L, first, len, tmask, r);
         return true;
     }
     return false;
@@ -778,18 +799,18 @@ RT_HD bool sphere_box_admits(double cx, double cy, double cz, double radius, V3 
 RT_COLD bool sphere_box_admits_cold(double cx, double cy, double cz, double radius, V3 o, V3 d) {
     return sphere_box_admits(cx, cy, cz, radius, o, d);
 }
-template <bool GENERAL, int MEDIUM>
+template <int GENERAL, int MEDIUM>
 RT_HD bool own_boxes_admit(const RtLaunch &L, uint32_t pi, V3 o, V3 d) {
     uint32_t kw = (uint32_t)RT_PRIM_SPHERE_T;
-    if (GENERAL || MEDIUM) kw = rec_at(L.prim_meta, pi).kind;
+    if (GENERAL || MEDIUM) kw = rec_at<GENERAL == 2>(L.prim_meta, pi).kind;
     const uint32_t kind = kw & 0xFFu;
     if (kind == RT_PRIM_SPHERE_T || kind == RT_PRIM_MEDIUM_T) {
-        const RtPrimGeo &G = (GENERAL || MEDIUM) ? rec_at(L.prim_geo, pi) : L.prim_geo[pi];
+        const RtPrimGeo &G = (GENERAL || MEDIUM) ? rec_at<GENERAL == 2>(L.prim_geo, pi) : L.prim_geo[pi];
         // (the spheres-only family has no other real call with arguments on the stack: inline there, it runs without scratch memory)
         return (GENERAL || MEDIUM) ? sphere_box_admits_cold(G.g[0], G.g[1], G.g[2], G.g[3], o, d) : sphere_box_admits(G.g[0], G.g[1], G.g[2], G.g[3], o, d);
     }
     if (GENERAL || MEDIUM)
-        return chain_boxes_admit<(MEDIUM >= 2)>(L.xforms, rec_at(L.prim_meta, pi).xform, (kw >> RT_META_CHAIN_SHIFT) & 0xFu,
+        return chain_boxes_admit<(MEDIUM >= 2)>(L.xforms_global, rec_at<GENERAL == 2>(L.prim_meta, pi).xform, (kw >> RT_META_CHAIN_SHIFT) & 0xFu,
                                                 (kw >> RT_META_TMASK_SHIFT) & 0xFu, o, d);
     return true;
 }
@@ -799,11 +820,11 @@ RT_HD bool own_boxes_admit(const RtLaunch &L, uint32_t pi, V3 o, V3 d) {
 // division for a rectangle) and re-check bounds that are known to hold.  A rectangle's world normal is a constant of the
 // leaf: the chain applied to (0, 0, 1), evaluated once at commit by the same expressions (rt_host.cpp, leaf_normal) and kept
 // in geo.g[2], geo.g[3], extra.e[0].  Media go through the full test (keyed draw, both boundary hits).
-template <bool GENERAL, int MEDIUM>
+template <int GENERAL, int MEDIUM>
 RT_HD void prim_record(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double t, SegCtx &sc, Rec *r) {
-    const RtPrimGeo &G = rec_at(L.prim_geo, pi);
+    const RtPrimGeo &G = rec_at<GENERAL == 2>(L.prim_geo, pi);
     uint32_t kw = (uint32_t)RT_PRIM_SPHERE_T;
-    if (GENERAL || MEDIUM) kw = rec_at(L.prim_meta, pi).kind;
+    if (GENERAL || MEDIUM) kw = rec_at<GENERAL == 2>(L.prim_meta, pi).kind;
     const uint32_t kind = kw & 0xFFu;
     if (kind == RT_PRIM_SPHERE_T) {
         const V3 c = mk(G.g[0], G.g[1], G.g[2]);
@@ -816,19 +837,19 @@ RT_HD void prim_record(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double t, Seg
             prim_hit<GENERAL, MEDIUM, true>(L, pi, o, d, dot(d, d), sc, r, false);
             return;
         }
-        const uint32_t first = rec_at(L.prim_meta, pi).xform, len = (kw >> RT_META_CHAIN_SHIFT) & 0xFu, tmask = (kw >> RT_META_TMASK_SHIFT) & 0xFu;
+        const uint32_t first = rec_at<GENERAL == 2>(L.prim_meta, pi).xform, len = (kw >> RT_META_CHAIN_SHIFT) & 0xFu, tmask = (kw >> RT_META_TMASK_SHIFT) & 0xFu;
         V3 lo = o, ld = d;
-        chain_down<(MEDIUM >= 2)>(L, first, len, tmask, &lo, &ld);
+        chain_down<(MEDIUM >= 2), GENERAL == 2>(L, first, len, tmask, &lo, &ld);
         if (kind == RT_PRIM_SPHERE_C) {
             sphere_finish(lo, ld, G.g[0], t, false, r);
-            chain_up<(MEDIUM >= 2)>(L, first, len, tmask, r);
+            chain_up<(MEDIUM >= 2), GENERAL == 2>(L, first, len, tmask, r);
         } else { // RT_PRIM_RECT_C: rect_hit's t, p (src/geometry.rs:160,176), the chain for the point, the leaf's normal
             r->t = t;
             r->u = 0.0;
             r->v = 0.0;
             r->p = lo + ld * t;
-            chain_up_point<(MEDIUM >= 2)>(L, first, len, tmask, &r->p);
-            r->n = mk(G.g[2], G.g[3], rec_at(L.prim_extra, pi).e[0]);
+            chain_up_point<(MEDIUM >= 2), GENERAL == 2>(L, first, len, tmask, &r->p);
+            r->n = mk(G.g[2], G.g[3], rec_at<GENERAL == 2>(L.prim_extra, pi).e[0]);
         }
     }
 }
@@ -967,7 +988,7 @@ RT_HD int32_t launch_n_prims(const RtLaunch &) {
 RT_HD int32_t launch_n_prims(const RtLaunch &L) { return L.n_prims; }
 #endif
 
-template <bool GENERAL, int MEDIUM, class Stack>
+template <int GENERAL, int MEDIUM, class Stack>
 RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack &st) {
     const bool near_plane = trav_ray_constants(L, o, d, tv);
     tv.best_t = RTL_INF;
@@ -1095,7 +1116,7 @@ RT_HD void trav_list_step(const float *boxes, uint32_t n, uint32_t first_prim, T
 }
 
 // one leaf step (tv.cur is a leaf reference): binary64 primitive test, then pop
-template <bool GENERAL, int MEDIUM, class Stack>
+template <int GENERAL, int MEDIUM, class Stack>
 RT_HD void trav_leaf_step(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack &st) {
     const uint32_t pi = tv.cur & Stack::Ref::kMask;
     const double a = dot(d, d);
@@ -1243,13 +1264,13 @@ RT_HD bool shade(const RtMaterial &M, V3 tex, const Rec &rec, V3 d_in, Rng &g, V
 // as the record: p = o' + d' t in the primitive's frame, unitSphereUv(p / r) (src/geometry.rs:66-70) or the
 // rectangle's ((x + w/2) / w, (y + h/2) / h) (src/geometry.rs:170-174); a medium's uv are the sums over its boundary
 // hits (src/volume.rs:64-66) and come out of the full medium test.
-template <bool GENERAL, int MEDIUM>
+template <int GENERAL, int MEDIUM>
 RT_HD void prim_uv(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double t, SegCtx &sc, double *u, double *v) {
-    const RtPrimGeo &G = rec_at(L.prim_geo, pi);
+    const RtPrimGeo &G = rec_at<GENERAL == 2>(L.prim_geo, pi);
     *u = 0.0;
     *v = 0.0;
     uint32_t kw = (uint32_t)RT_PRIM_SPHERE_T;
-    if (GENERAL || MEDIUM) kw = rec_at(L.prim_meta, pi).kind;
+    if (GENERAL || MEDIUM) kw = rec_at<GENERAL == 2>(L.prim_meta, pi).kind;
     const uint32_t kind = kw & 0xFFu;
     if (kind == RT_PRIM_SPHERE_T) {
         const V3 oc = o - mk(G.g[0], G.g[1], G.g[2]);
@@ -1267,9 +1288,9 @@ RT_HD void prim_uv(const RtLaunch &L, uint32_t pi, V3 o, V3 d, double t, SegCtx 
             }
             return;
         }
-        const RtPrimMeta &P = rec_at(L.prim_meta, pi);
+        const RtPrimMeta &P = rec_at<GENERAL == 2>(L.prim_meta, pi);
         V3 lo = o, ld = d;
-        chain_down<(MEDIUM >= 2)>(L, P.xform, (kw >> RT_META_CHAIN_SHIFT) & 0xFu, (kw >> RT_META_TMASK_SHIFT) & 0xFu, &lo, &ld);
+        chain_down<(MEDIUM >= 2), GENERAL == 2>(L, P.xform, (kw >> RT_META_CHAIN_SHIFT) & 0xFu, (kw >> RT_META_TMASK_SHIFT) & 0xFu, &lo, &ld);
         if (kind == RT_PRIM_SPHERE_C) {
             sphere_uv((lo + ld * t) / G.g[0], u, v);
         } else {
@@ -1308,7 +1329,7 @@ RT_HD void start_sample(const LaunchT &L, uint32_t x, uint32_t y, uint32_t s, Pa
     ps->k = 0;
 }
 
-template <bool GENERAL, int MEDIUM, bool TEXTURED, class Stack>
+template <int GENERAL, int MEDIUM, bool TEXTURED, class Stack>
 RT_HD void begin_segment(const RtLaunch &L, PathState *ps, Trav &tv, Stack &st, unsigned long long *prims_tested) {
     SegCtx sc;
     sc.r2a = RTL_NAN; // set by trav_begin
@@ -1321,7 +1342,7 @@ RT_HD void begin_segment(const RtLaunch &L, PathState *ps, Trav &tv, Stack &st, 
     *prims_tested += sc.prims_tested;
 }
 
-template <bool GENERAL, int MEDIUM, bool TEXTURED, class Stack>
+template <int GENERAL, int MEDIUM, bool TEXTURED, class Stack>
 RT_HD void leaf_step(const RtLaunch &L, PathState *ps, Trav &tv, Stack &st, unsigned long long *prims_tested) {
     SegCtx sc;
     sc.r2a = tv.r2a;
@@ -1340,14 +1361,14 @@ RT_HD void leaf_step(const RtLaunch &L, PathState *ps, Trav &tv, Stack &st, unsi
 // radiance in *radiance.
 // ball_iters > 0 bounds the rejection sampler of this call; when the bound is hit *pending is set, nothing but the
 // stream has advanced and the same hit has to be finished again (the kernel does so in its next shade block).
-template <bool GENERAL, int MEDIUM, bool TEXTURED>
+template <int GENERAL, int MEDIUM, bool TEXTURED>
 RT_HD bool finish_segment(const RtLaunch &L, PathState *ps, const Trav &tv, V3 *radiance, int ball_iters = 0, bool *pending = nullptr) {
     *radiance = mk(0.0, 0.0, 0.0);
     if (tv.best_prim == 0xFFFFFFFFu) return true; // background is black (src/render.rs:21-28)
     const uint32_t prim = tv.best_prim;
-    const uint32_t mat = (GENERAL || MEDIUM) ? rec_at(L.prim_meta, prim).material : L.prim_meta[prim].material;
+    const uint32_t mat = (GENERAL || MEDIUM) ? rec_at<GENERAL == 2>(L.prim_meta, prim).material : L.prim_meta[prim].material;
     if (mat == RT_NO_MATERIAL) return true; // src/render.rs:18-20
-    const RtMaterial &M = (GENERAL || MEDIUM) ? rec_at(L.materials, mat) : L.materials[mat];
+    const RtMaterial &M = (GENERAL || MEDIUM) ? rec_at<GENERAL == 2>(L.materials, mat) : L.materials[mat];
     SegCtx sc;
     sc.r2a = RTL_NAN; // the record is built at the known t: no roots
     sc.rng_base = ps->g.base;

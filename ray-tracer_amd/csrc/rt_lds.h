@@ -55,6 +55,10 @@ RT_LDS_HD constexpr uint32_t rt_swap_cap_effective(uint32_t block_threads, uint3
 // washes through the L1 -- the table's entry was an L2 access on the critical path of a call (book-two cover: +2 %).
 #define RT_LDS_LOG_TABLE_BYTES 2048u
 RT_LDS_HD constexpr uint32_t rt_lds_front_bytes(bool media_family) { return media_family ? RT_LDS_LOG_TABLE_BYTES : 0u; }
+// Box-LIST scenes whose records -- transforms, prims, materials -- fit (RT_LIST_SCENE_MAX, and the workgroup's LDS share with the
+// smallest queues: rt_api.cpp render_range): the records follow the table, in whole 256-byte steps (the stack behind them stays
+// 256-byte aligned).  Other LIST scenes keep their records in global memory.
+RT_LDS_HD constexpr uint32_t rt_lds_scene_room(uint32_t scene_bytes) { return (scene_bytes + 255u) & ~255u; }
 
 // front_bytes: rt_lds_front_bytes of the family; node_bytes: 0 when the node array stays in global memory; swap_cap: 0 for the
 // kernels without swap queues

@@ -233,6 +233,7 @@ extern "C" int rt_probe_traverse(rt_scene *s, const void *rays_host, int n, int 
     L.prim_geo = (const RtPrimGeo *)s->d_prim_geo;
     L.prim_extra = (const RtPrimExtra *)s->d_prim_extra;
     L.xforms = s->d_xforms ? (const RtXform *)((const unsigned char *)s->d_xforms + s->flat.xform_store_offset()) : nullptr;
+    L.xforms_global = L.xforms;
     L.materials = (const RtMaterial *)s->d_materials;
     L.textures = (const RtTexture *)s->d_textures;
     L.image_blob = (const uint8_t *)s->d_blob;

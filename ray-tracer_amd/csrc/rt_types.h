@@ -11,6 +11,10 @@
 #define RT_STACK_DEPTH 24   /* traversal stack entries per lane; the builder bounds the tree depth to this */
 #define RT_MAX_HOISTED 4    /* scene-filling prims tested up front instead of through the BVH */
 #define RT_LIST_MAX 24      /* general scenes of up to this many BVH leaves are walked as a box LIST (rtl::trav_list_step) */
+#define RT_LIST_SCENE_MAX 12288 /* a LIST scene whose records (transforms, prims, materials) fit this many bytes AND the workgroup's LDS share keeps them in LDS */
+#ifndef RT_LIST_LDS_ARRAYS
+#define RT_LIST_LDS_ARRAYS 0x1F /* which of them are READ there: 1 xforms, 2 prim_geo, 4 prim_meta, 8 prim_extra, 16 materials (A/B knob) */
+#endif
 #define RT_LIST_BOX_FLOATS 9 /* one list box: {lo, hi, lo} per axis -- entry plane at [s], exit plane at [s + 1], s = sign bit of 1/d */
 #define RT_MAX_CHAIN 4      /* transform levels above one leaf (Sprite > BVH > Sprite > TransformedGeometry ...) every kernel family unrolls */
 #define RT_MAX_CHAIN_DEEP 15 /* levels the family for general media / deep chains walks (the ones beyond RT_MAX_CHAIN in a run-time loop) */
@@ -158,6 +162,14 @@ struct RtLaunch {
     const RtMaterial *materials;
     const RtTexture *textures;
     const uint8_t *image_blob;
+    // Box-LIST scenes whose records fit (lds_mode bit 4, kernels with RECLDS): the scene's records live in the workgroup's LDS.  prim_meta, prim_geo, prim_extra, xforms and
+    // materials above then hold the arrays' BYTE OFFSETS in the LDS instead of addresses (rtl::rec_at<true>), and the kernel
+    // copies `scene_bytes` bytes from `scene_blob` -- the five arrays packed by the host in that layout -- to offset
+    // `scene_lds_off` at entry.  `xforms_global` is the transform array in global memory in every mode: the per-level boxes in
+    // front of it are read there by the one cold path that needs them (rtl::chain_boxes_admit).
+    const unsigned char *scene_blob;
+    const RtXform *xforms_global;
+    uint32_t scene_bytes, scene_lds_off;
     int32_t n_nodes;       // RtNode records behind `nodes` (in list mode: the packed box list, rounded up to whole records)
     int32_t n_list;        // 0: BVH walk.  > 0: `nodes` holds this many list boxes (RT_LIST_BOX_FLOATS binary32 each), leaf i = prim n_hoisted + i
     int32_t stack_entries; // LDS stack entries per lane for this scene (tree depth + 1, <= RT_STACK_DEPTH)

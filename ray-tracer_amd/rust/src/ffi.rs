@@ -82,6 +82,7 @@ pub struct rt_launch_config {
     pub swap_cap: c_int,
     pub waves_per_simd: c_int,
     pub tile_order: c_int,
+    pub records_in_lds: c_int,
 }
 
 #[repr(C)]

@@ -191,6 +191,27 @@ def cornell(aspect: float = 1.0) -> SceneDesc:
     return d
 
 
+def cube_row(n_cubes: int, levels: int = 1, aspect: float = 1.0) -> SceneDesc:
+    """n_cubes rotated boxes (6 leaves each) over a floor, under a light: small general scenes around the limits of the box-LIST walk
+    (24 leaves) and of the records the LIST kernels keep in LDS (tests); levels > 1 nests every cube in that many TransformedGeometry
+    levels (examples/cornell-box.rs:114-133 builds its boxes the same way, with one level)."""
+    d = SceneDesc(name=f"cube-row-{n_cubes}x{levels}")
+    white = d.lambertian_rgb((0.73, 0.73, 0.73))
+    blue = d.lambertian_rgb((0.2, 0.3, 0.7))
+    light = d.mat("diffuse_light", d.tex_solid((7.0, 7.0, 7.0)))
+    ex, ey = (1.0, 0.0, 0.0), (0.0, 1.0, 0.0)
+    d.sprite(d.geom("rectangle", 900.0, 900.0), white, mat4_multiplied(mat4_translation((0.0, 0.0, 0.0)), mat4_rotation(radians(-90.0), ex)))
+    d.sprite(d.geom("rectangle", 400.0, 400.0), light, mat4_multiplied(mat4_translation((0.0, 500.0, 0.0)), mat4_rotation(radians(90.0), ex)))
+    for i in range(n_cubes):
+        g = d.geom("cube", 90.0, 120.0 + 25.0 * i, 90.0)
+        for k in range(levels - 1):
+            g = d.geom("transformed", g, mat4_multiplied(mat4_translation((3.0 * (k + 1), 0.0, -2.0 * k)), mat4_rotation(radians(4.0 + 3.0 * k), ey)))
+        x = -60.0 * (n_cubes - 1) + 120.0 * i
+        d.sprite(g, blue if i % 2 else white, mat4_multiplied(mat4_translation((x, 60.0 + 12.5 * i, 30.0 * (i % 3))), mat4_rotation(radians(-20.0 + 17.0 * i), ey)))
+    d.camera = ((0.0, 260.0, -900.0), (0.0, 120.0, 0.0), (0.0, 1.0, 0.0), radians(40.0), float(aspect), 10.0, 0.0)
+    return d
+
+
 # ------------------------------------------------------------------ book-two cover
 def earth_texture(w: int = 1024, h: int = 512) -> np.ndarray:
     """Deterministic procedural stand-in for ./earthmap.jpg (absent upstream, examples/main.rs:266)."""

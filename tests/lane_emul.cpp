@@ -192,6 +192,7 @@ extern "C" int lane_emul_render(rt_scene *s, const rt_camera *cam, int W, int H,
     L.prim_geo = s->flat.prim_geo.data();
     L.prim_extra = s->flat.prim_extra.data();
     L.xforms = s->flat.xforms_in_store();
+    L.xforms_global = L.xforms;
     L.materials = s->flat.materials.data();
     L.textures = s->flat.textures.data();
     L.image_blob = s->flat.image_blob.data();
@@ -307,6 +308,31 @@ extern "C" void lane_emul_lds_layout(unsigned stack_entries, unsigned block, uns
 }
 
 // ---- which arithmetic this build carries, and its pieces one at a time ----
+// The records a box-LIST kernel copies into LDS (FlatScene::scene_blob, rtl::rec_at<true>): 0 when the blob holds every array byte
+// for byte at a 16-byte offset, -1 when the scene has none (not a list scene, or more than RT_LIST_SCENE_MAX bytes), else the
+// number of the first array that is wrong.  *bytes_out = the blob's size.
+extern "C" int lane_emul_scene_blob_check(rt_scene *s, unsigned *bytes_out, int *n_list_out) {
+    const rt::FlatScene &f = s->flat;
+    *bytes_out = (unsigned)f.scene_blob.size();
+    *n_list_out = f.n_list;
+    if (f.scene_blob.empty()) return -1;
+    struct Arr { const void *p; size_t bytes; } arr[5] = {{f.xforms.data(), f.xforms.size() * sizeof(RtXform)},
+                                                            {f.prim_geo.data(), f.prim_geo.size() * sizeof(RtPrimGeo)},
+                                                            {f.prim_meta.data(), f.prim_meta.size() * sizeof(RtPrimMeta)},
+                                                            {f.prim_extra.data(), f.prim_extra.size() * sizeof(RtPrimExtra)},
+                                                            {f.materials.data(), f.materials.size() * sizeof(RtMaterial)}};
+    size_t end = 0;
+    for (int k = 0; k < 5; ++k) {
+        const size_t off = f.scene_blob_off[k];
+        if (off % 16 != 0 || off < end || off + arr[k].bytes > f.scene_blob.size()) return k + 1;
+        if (arr[k].bytes && std::memcmp(f.scene_blob.data() + off, arr[k].p, arr[k].bytes) != 0) return k + 1;
+        end = off + arr[k].bytes;
+    }
+    if (f.scene_blob.size() % 16 != 0 || f.scene_blob.size() > (size_t)RT_LIST_SCENE_MAX) return 6;
+    if (f.prim_geo.size() != f.prim_meta.size() || f.prim_extra.size() != f.prim_meta.size()) return 7;
+    return 0;
+}
+
 extern "C" int lane_emul_device_math(void) {
 #if defined(RT_EMULATE_DEVICE_MATH)
     return 1;

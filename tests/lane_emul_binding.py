@@ -71,6 +71,16 @@ def load(name):
         names = ("stack_off", "node_off", "job_off", "swap_off", "swap_class_bytes", "total", "aligned", "cap", "cap_effective")
         return dict(zip(names, [int(v) for v in out]))
 
+    _LIB.lane_emul_scene_blob_check.restype = C.c_int
+    _LIB.lane_emul_scene_blob_check.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_int)]
+
+    def scene_blob_check(scene):
+        """the records a box-LIST kernel keeps in LDS (FlatScene::scene_blob) -> (verdict, bytes, n_list): verdict 0 = every array
+        is in the blob byte for byte at a 16-byte offset, -1 = the scene has no blob"""
+        nbytes, n_list = C.c_uint(), C.c_int()
+        v = _LIB.lane_emul_scene_blob_check(scene._h, C.byref(nbytes), C.byref(n_list))
+        return int(v), int(nbytes.value), int(n_list.value)
+
     _U64P = C.POINTER(C.c_uint64)
     _LIB.lane_emul_device_math.restype = C.c_int
     _LIB.lane_emul_set_rcp_mode.argtypes = [C.c_int]
@@ -141,7 +151,7 @@ def load(name):
     ns = types.SimpleNamespace(render=render, ball_check=ball_check, medium_forms=medium_forms, lds_layout=lds_layout, div3=div3,
                                sphere_roots=sphere_roots, sphere_t_world=sphere_t_world, rng_forms=rng_forms,
                                device_math=bool(_LIB.lane_emul_device_math()), set_rcp_mode=_LIB.lane_emul_set_rcp_mode,
-                               rcp_calls=lambda: int(_LIB.lane_emul_rcp_calls()), trace_pixel=trace_pixel, trace_segments=trace_segments, world_hit=world_hit, set_log_perturbation=_LIB.lane_emul_set_log_perturbation, name=name)
+                               rcp_calls=lambda: int(_LIB.lane_emul_rcp_calls()), trace_pixel=trace_pixel, trace_segments=trace_segments, world_hit=world_hit, scene_blob_check=scene_blob_check, set_log_perturbation=_LIB.lane_emul_set_log_perturbation, name=name)
     return ns
 
 

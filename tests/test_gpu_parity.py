@@ -904,6 +904,30 @@ def test_a_shard_learns_its_tile_order_and_the_image_does_not_change(rt, scenes,
     sc.status()
 
 
+def test_small_general_scenes_with_their_records_in_lds(rt, scenes, oracle, gpu_device, monkeypatch):
+    """Box-LIST scenes (<= 24 leaves) whose transform / prim / material records fit keep them in the workgroup's LDS
+    (`rt_launch_config.records_in_lds`, rtl::rec_at<true>); the others -- too many records, or the kernels without the swap queues
+    -- read them from global memory as before.  Same arithmetic either way: every picture equals the oracle's bit for bit."""
+    W, H, spp, depth = 96, 96, 8, 50
+    seen = {}
+    for d in (scenes.cornell(), scenes.cube_row(2), scenes.cube_row(3), scenes.cube_row(3, levels=2), scenes.cube_row(3, levels=4), scenes.cube_row(5)):
+        sc, cam = scenes.build_product(d, device=gpu_device)
+        img = sc.render(cam, W, H, spp, depth, seed=3)
+        seen[d.name] = sc.last_launch_config()["records_in_lds"]
+        ref = oracle.build_oracle(d).render(W, H, spp, depth, seed=3, iterative=True, nthreads=8)
+        assert np.array_equal(img, ref), d.name
+        assert img.mean() > 0.01, d.name  # (lit: the comparison is not of two black pictures)
+        sc.close()
+    assert seen["cornell-box"] == 1 and seen["cube-row-2x1"] == 1, seen
+    assert seen["cube-row-3x4"] == 0 and seen["cube-row-5x1"] == 0, seen  # > 12 KiB of records; not a list scene
+    monkeypatch.setenv("RT_SWAP", "0")
+    d = scenes.cornell()
+    sc, cam = scenes.build_product(d, device=gpu_device)
+    img = sc.render(cam, W, H, spp, depth, seed=3)
+    assert sc.last_launch_config()["records_in_lds"] == 0
+    assert np.array_equal(img, oracle.build_oracle(d).render(W, H, spp, depth, seed=3, iterative=True, nthreads=8))
+
+
 def test_sweep_scene_78971_on_the_gpu(rt, scenes, oracle, gpu_device):
     """the scene of the 60 000-scene sweep whose 35-bounce path inside a scaled medium lost the medium at |d| = 1e-38"""
     from test_random_scenes import random_scene_r3

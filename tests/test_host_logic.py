@@ -449,3 +449,17 @@ def test_lds_layout_is_aligned_and_fits_for_every_launch_shape(lane_emul):
     # the case the advisor named: ~250 leaves with the node array in LDS used to get 39 entries; now an even 38
     l = lane_emul.lds_layout(12, 256, 4, 250 * 64, 4)
     assert l["cap"] % 2 == 0
+
+
+def test_scene_records_blob_of_list_scenes(scenes, lane_emul):
+    """Small general scenes (box-LIST walk, <= 24 leaves) carry their transform / prim / material records a second time as ONE
+    packed blob that the LIST kernels copy into LDS (rtl::rec_at<true>): every array byte for byte at a 16-byte offset, at most
+    RT_LIST_SCENE_MAX (12 KiB) in all.  A list scene with more records has no blob (its records stay in global memory), a scene
+    that is not walked as a list has none either."""
+    for d, want_list, want_blob in ((scenes.cornell(), 18, True), (scenes.cube_row(2), 14, True), (scenes.cube_row(3, levels=1), 20, True),
+                                    (scenes.cube_row(3, levels=4), 20, False), (scenes.cube_row(5), 0, False), (scenes.book_one(1, 1.5), 0, False)):
+        sc, _ = scenes.build_product(d, device=-1)
+        verdict, nbytes, n_list = lane_emul.scene_blob_check(sc)
+        assert n_list == want_list, (d.name, n_list)
+        assert (verdict == 0 and 0 < nbytes <= 12288 and nbytes % 16 == 0) if want_blob else (verdict == -1 and nbytes == 0), (d.name, verdict, nbytes)
+        sc.close()
