@@ -454,7 +454,7 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     // stack), and the swap-at-shade queues with as many entries as are left (16 at least)
     const unsigned block = (unsigned)rt_kernel_block_size(feat);
     const int wide = s->flat.wide ? 1 : 0;
-    const unsigned entry_bytes = wide ? 8u : 4u;
+    const unsigned entry_bytes = s->flat.n_list > 0 ? 2u : (wide ? 8u : 4u); // (rt_kernels.hip StackOf)
     const unsigned node_bytes = (unsigned)(s->flat.nodes.size() * sizeof(RtNode));
     const char *no_lds = std::getenv("RT_NO_LDS_NODES");
     // RT_SWAP=0 selects the kernels without the queues (A/B runs)

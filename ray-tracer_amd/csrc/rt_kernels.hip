@@ -26,8 +26,8 @@
 //   The traversal stack lives in LDS, [depth][thread], conflict-free ds_read/write_b32.
 //   Six kernel families are instantiated from this one template (VGPRs / scratch bytes per lane / waves per SIMD of the timed
 //   builds, csrc/_obj/resource_usage.txt): spheres only (book-one: 120 / 0 / 4, 512-thread groups, two per CU); lean general
-//   -- matrices, rectangles, cubes, node geometries -- (Cornell box, walked as a box list: 127 / 64 / 4, 256-thread groups,
-//   four per CU); general + sphere media + textures (book-two cover: 128 / 64 / 4); media over general boundaries and chains of
+//   -- matrices, rectangles, cubes, node geometries -- (Cornell box, walked as a box list with its transform / prim / material
+//   records in LDS and half-word stack entries: 128 / 64 / 4, 256-thread groups, four per CU); general + sphere media + textures (book-two cover: 128 / 64 / 4); media over general boundaries and chains of
 //   5-15 transform levels (168 / 352 / 3); media inside the boundary of media (168 / 2160 / 3, its own compilation); and each of
 //   the general ones with 32-bit node references (> 32 767 prims or nodes).  The scratch bytes of the first three belong to
 //   real calls on paths that hardly ever run (transcendentals, the reference's boxes for rays in an axis plane: rt_lane.h).
@@ -185,13 +185,38 @@ struct LdsStackWide {
         *ref = e.y;
     }
 };
-template <int BLOCK, bool WIDE>
+// Box-LIST scenes (<= 24 leaves, prim indices below 64: rt_host.cpp): half a word per entry = ten bits of tnear (exponent + two
+// mantissa bits, rounded DOWN: a lower bound, as the 16-bit form's is; tnear >= 0, so the sign bit is not stored) | six of the
+// leaf's prim index.  Only the list step pushes and it pushes leaves only.  The 17 entries of the Cornell box are 8.5 KB per
+// 256-thread group instead of 17: room for queues of 60 entries beside the scene's records (rtl::rec_at<true>).
+template <int BLOCK>
+struct LdsStackList {
+    typedef RtRef16 Ref;
+    static constexpr unsigned kEntryBytes = 2;
+    uint16_t *base;
+    __device__ __forceinline__ void set(unsigned char *lds) { base = reinterpret_cast<uint16_t *>(lds) + threadIdx.x; }
+    __device__ __forceinline__ void push(int32_t &sp, float tnear, uint32_t ref) {
+        base[sp * BLOCK] = (uint16_t)(((__float_as_uint(tnear) >> 21) << 6) | (ref & 63u));
+        ++sp;
+    }
+    __device__ __forceinline__ void pop(int32_t &sp, float *tnear, uint32_t *ref) {
+        --sp;
+        const uint32_t e = base[sp * BLOCK];
+        *tnear = __uint_as_float((e >> 6) << 21);
+        *ref = Ref::kLeaf | (e & 63u);
+    }
+};
+template <int BLOCK, bool WIDE, bool LIST>
 struct StackOf {
     typedef LdsStack<BLOCK> type;
 };
 template <int BLOCK>
-struct StackOf<BLOCK, true> {
+struct StackOf<BLOCK, true, false> {
     typedef LdsStackWide<BLOCK> type;
+};
+template <int BLOCK>
+struct StackOf<BLOCK, false, true> {
+    typedef LdsStackList<BLOCK> type;
 };
 // workgroup size and waves per SIMD of each kernel family
 __host__ __device__ constexpr int block_of(bool general, int medium) {
@@ -259,9 +284,9 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) { // set 
 // first active lane's value, for values that are the same in every lane
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-// Dynamic LDS: [stack_entries][RT_BLOCK] traversal stack, then (LDSNODES) a copy of the
-// whole node array: node steps are a dependent pointer chase, and an LDS read returns
-// in ~1/4 of an L2 hit.
+// Dynamic LDS (rt_lds.h): [the family's table][a list scene's records][stack_entries][block] traversal stack, then (LDSNODES) a
+// copy of the whole node array -- node steps are a dependent pointer chase, and an LDS read returns in ~1/4 of an L2 hit -- then
+// the waves' job state and the class queues.
 extern __shared__ __attribute__((aligned(16))) unsigned char rt_lds[];
 
 // LIST: the scene's leaves are a box list in LDS instead of a tree (small general scenes, rtl::trav_list_step)
@@ -271,7 +296,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
     // the lane program's GENERAL: 0 spheres only, 1 general prims with their records in global memory, 2 (RECLDS: box-LIST scenes
     // whose records fit) with the records in this workgroup's LDS (rt_lane.h rec_at<true>)
     constexpr int G = GENERAL ? (RECLDS ? 2 : 1) : 0;
-    typedef typename StackOf<kBlock, WIDE>::type Stack;
+    typedef typename StackOf<kBlock, WIDE, LIST>::type Stack;
     typedef typename Stack::Ref Ref;
     // entries per class queue: the most (<= RT_SWAP_CAP) that leaves the kernel family's full occupancy resident (host)
     // (a compile-time constant for the 512-thread families: the address arithmetic of a run-time capacity costs the

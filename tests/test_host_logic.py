@@ -433,7 +433,7 @@ def test_lds_layout_is_aligned_and_fits_for_every_launch_shape(lane_emul):
     capacity is above the 16-entry floor."""
     nq = 3  # the three class queues: the layout has no other (rt_lds.h)
     for block, groups, front in ((512, 2, 0), (256, 4, 0), (256, 3, 0), (256, 4, 2048), (256, 3, 2048)):  # front: the log table of the media families
-        for entry_bytes in (4, 8):
+        for entry_bytes in (2, 4, 8):
             for stack_entries in range(1, 25):
                 for node_bytes in (0, 64, 576, 648, 1024, 9 * 64, 250 * 64, 484 * 64, 1000 * 64):
                     l = lane_emul.lds_layout(stack_entries, block, entry_bytes, node_bytes, groups, front)
