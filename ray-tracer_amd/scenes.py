@@ -212,6 +212,23 @@ def cube_row(n_cubes: int, levels: int = 1, aspect: float = 1.0) -> SceneDesc:
     return d
 
 
+def slab_stack(n: int = 22, aspect: float = 1.0) -> SceneDesc:
+    """n parallel rectangles one behind the other, every second one a mirror, lit from the front: a camera ray crosses the boxes of
+    ALL of them, so the box-list walk pushes n - 1 entries -- the deepest a list scene's stack gets (tests)."""
+    d = SceneDesc(name=f"slab-stack-{n}")
+    white = d.lambertian_rgb((0.8, 0.8, 0.8))
+    mirror = d.mat("metal", d.tex_solid((0.9, 0.9, 0.9)), 0.0)
+    light = d.mat("diffuse_light", d.tex_solid((4.0, 4.0, 4.0)))
+    ey = (0.0, 1.0, 0.0)
+    d.sprite(d.geom("rectangle", 60.0, 60.0), light, mat4_multiplied(mat4_translation((0.0, 0.0, -40.0)), mat4_rotation(radians(180.0), ey)))
+    for i in range(n - 1):
+        size = 6.0 + 2.0 * i  # the nearer ones are smaller: every one is seen past the edges of those in front
+        d.sprite(d.geom("rectangle", size, size), mirror if i % 2 else white,
+                 mat4_multiplied(mat4_translation((0.3 * i, -0.2 * i, 3.0 * i)), mat4_rotation(radians(180.0 + 2.0 * i), ey)))  # (normals towards the camera)
+    d.camera = ((0.0, 0.0, -30.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), radians(50.0), float(aspect), 10.0, 0.0)
+    return d
+
+
 # ------------------------------------------------------------------ book-two cover
 def earth_texture(w: int = 1024, h: int = 512) -> np.ndarray:
     """Deterministic procedural stand-in for ./earthmap.jpg (absent upstream, examples/main.rs:266)."""

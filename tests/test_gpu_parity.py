@@ -910,7 +910,9 @@ def test_small_general_scenes_with_their_records_in_lds(rt, scenes, oracle, gpu_
     -- read them from global memory as before.  Same arithmetic either way: every picture equals the oracle's bit for bit."""
     W, H, spp, depth = 96, 96, 8, 50
     seen = {}
-    for d in (scenes.cornell(), scenes.cube_row(2), scenes.cube_row(3), scenes.cube_row(3, levels=2), scenes.cube_row(3, levels=4), scenes.cube_row(5)):
+    # (slab_stack: every camera ray crosses all 20 list boxes -- the list kernels' half-word stack at its deepest, 19 entries)
+    for d in (scenes.cornell(), scenes.cube_row(2), scenes.cube_row(3), scenes.cube_row(3, levels=2), scenes.cube_row(3, levels=4), scenes.cube_row(5),
+              scenes.slab_stack(22)):
         sc, cam = scenes.build_product(d, device=gpu_device)
         img = sc.render(cam, W, H, spp, depth, seed=3)
         seen[d.name] = sc.last_launch_config()["records_in_lds"]
@@ -918,7 +920,7 @@ def test_small_general_scenes_with_their_records_in_lds(rt, scenes, oracle, gpu_
         assert np.array_equal(img, ref), d.name
         assert img.mean() > 0.01, d.name  # (lit: the comparison is not of two black pictures)
         sc.close()
-    assert seen["cornell-box"] == 1 and seen["cube-row-2x1"] == 1, seen
+    assert seen["cornell-box"] == 1 and seen["cube-row-2x1"] == 1 and seen["slab-stack-22"] == 1, seen
     assert seen["cube-row-3x4"] == 0 and seen["cube-row-5x1"] == 0, seen  # > 12 KiB of records; not a list scene
     monkeypatch.setenv("RT_SWAP", "0")
     d = scenes.cornell()

@@ -463,3 +463,16 @@ def test_scene_records_blob_of_list_scenes(scenes, lane_emul):
         assert n_list == want_list, (d.name, n_list)
         assert (verdict == 0 and 0 < nbytes <= 12288 and nbytes % 16 == 0) if want_blob else (verdict == -1 and nbytes == 0), (d.name, verdict, nbytes)
         sc.close()
+
+
+def test_the_deepest_stack_of_a_list_scene(scenes, oracle, lane_emul):
+    """scenes.slab_stack: parallel rectangles one behind the other -- a camera ray crosses the culling boxes of all of them, so the
+    box-list walk pushes every box but the nearest (n_list - 1 entries, what rt_api.cpp sizes a list scene's stack for) and pops them
+    against the shrinking best hit; the picture equals the oracle's."""
+    d = scenes.slab_stack(22)
+    sc, cam = scenes.build_product(d, device=-1)
+    n_list = lane_emul.scene_blob_check(sc)[2]
+    assert n_list == 20  # (22 leaves, two of them scene-filling: tested directly, not in the list)
+    img, _, high_water = lane_emul.render(sc, cam, 64, 64, 4, 30, seed=2)
+    assert high_water == n_list - 1
+    assert np.array_equal(img, oracle.build_oracle(d).render(64, 64, 4, 30, seed=2, iterative=True, nthreads=8)) and img.mean() > 0.1
