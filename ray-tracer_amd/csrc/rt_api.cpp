@@ -541,7 +541,8 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     if (const char *t = std::getenv("RT_TEST_TILE_ORDER_LEVELS")) order_levels = std::atoi(t);
     if (const char *t = std::getenv("RT_TEST_TILE_ORDER_WHOLE")) order_whole = *t == '1';
 #endif
-    if ((p->shard_count > 1 || order_whole) && !(p->flags & RT_FLAG_ASCENDING_TILES) && !accumulate && finalize && n_owned >= 64 && n_owned <= 65536) {
+    // (sample ranges of a progressive render are renders of the same view: the first range learns, the later ones use the order)
+    if ((p->shard_count > 1 || order_whole) && !(p->flags & RT_FLAG_ASCENDING_TILES) && n_owned >= 64 && n_owned <= 65536) {
         order_key = view_key(cam, p);
         if (to.key == order_key && to.n == n_owned) {
             if (!to.complete && hipEventQuery(to.ready) == hipSuccess) to.complete = true;

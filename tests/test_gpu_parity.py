@@ -626,6 +626,19 @@ def test_progressive_render_is_bit_identical(rt, scenes, gpu_device):
     sc2.render_progressive(cam2, W, H, spp, 50, 4, 7, 8, sums)
     sc2.render_progressive(cam2, W, H, spp, 50, 4, 8, 20, sums)
     assert np.array_equal(sums / spp, whole)
+    # a shard rendered in ranges: the first range learns the shard's tile order, the later ones use it; the sums are the same
+    W2, H2 = 320, 240
+    d2 = scenes.book_one(1, W2 / H2)
+    sc3, cam3 = scenes.build_product(d2, device=gpu_device)
+    part = sc3.render(cam3, W2, H2, 12, 50, seed=4, shard=(1, 2))
+    sc4, cam4 = scenes.build_product(d2, device=gpu_device)
+    sums2 = np.zeros((H2, W2, 3))
+    modes = []
+    for a, b in ((0, 4), (4, 9), (9, 12)):
+        sc4.render_progressive(cam4, W2, H2, 12, 50, 4, a, b, sums2, shard=(1, 2))
+        modes.append(sc4.last_launch_config()["tile_order"])
+    assert modes == [rt.RT_TILE_ORDER_LEARNING, rt.RT_TILE_ORDER_LEARNT, rt.RT_TILE_ORDER_LEARNT], modes
+    assert np.array_equal(sums2 / 12, part)
     with pytest.raises(rt.RtError):
         sc2.render_progressive(cam2, W, H, spp, 50, 4, 5, 5, sums)
     with pytest.raises(rt.RtError):
