@@ -58,6 +58,50 @@ struct LdsStack16 {
         *ref = e & 0xFFFFu;
     }
 };
+// ---- a 4-wide tree (round 4, second question): the cover family waits for the L2 on every node step (docs/experiments.md 1.5); a
+// node with four children halves the number of DEPENDENT fetches per ray.  Built here from the scene's binary tree (the larger inner
+// child of a node is replaced by its own two children until there are four or none is left), same binary32 culling boxes.
+struct RtNode4 { // 128 bytes: per axis the four children's lower planes, then their upper planes; then the references
+    float lo_x[4], hi_x[4], lo_y[4], hi_y[4], lo_z[4], hi_z[4];
+    uint32_t child[4]; // RtRef16 references; kNoChild4 for an empty slot
+    uint32_t pad[4];
+};
+constexpr uint32_t kNoChild4 = 0xFFFFFFFFu;
+template <class Stack>
+__device__ __forceinline__ void node4_step(const RtNode4 *nodes4, rtl::Trav &tv, Stack &st) {
+    const unsigned char *N = reinterpret_cast<const unsigned char *>(nodes4) + tv.cur * 128u;
+    // the entry plane of an axis is the lower one exactly when the binary tree's cursor offsets say so (rtl::trav_ray_constants)
+    const uint32_t sx = tv.ox == 0u ? 0u : 16u, sy = tv.oy == 8u ? 0u : 16u, sz = tv.oz == 16u ? 0u : 16u;
+    const float4 ex = *reinterpret_cast<const float4 *>(N + sx), qx = *reinterpret_cast<const float4 *>(N + (sx ^ 16u));
+    const float4 ey = *reinterpret_cast<const float4 *>(N + 32u + sy), qy = *reinterpret_cast<const float4 *>(N + 32u + (sy ^ 16u));
+    const float4 ez = *reinterpret_cast<const float4 *>(N + 64u + sz), qz = *reinterpret_cast<const float4 *>(N + 64u + (sz ^ 16u));
+    const uint4 ch = *reinterpret_cast<const uint4 *>(N + 96u);
+    const float pex[4] = {ex.x, ex.y, ex.z, ex.w}, pey[4] = {ey.x, ey.y, ey.z, ey.w}, pez[4] = {ez.x, ez.y, ez.z, ez.w};
+    const float pqx[4] = {qx.x, qx.y, qx.z, qx.w}, pqy[4] = {qy.x, qy.y, qy.z, qy.w}, pqz[4] = {qz.x, qz.y, qz.z, qz.w};
+    const uint32_t c[4] = {ch.x, ch.y, ch.z, ch.w};
+    float tmin[4];
+    bool hit[4];
+    uint32_t near_c = kNoChild4;
+    float near_t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        tmin[i] = fmaxf(fmaxf(fmaf(pex[i], tv.idx, tv.nx), fmaf(pey[i], tv.idy, tv.ny)), fmaxf(fmaf(pez[i], tv.idz, tv.nz), 0.0f));
+        const float tmax = fminf(fminf(fmaf(pqx[i], tv.idx, tv.fx), fmaf(pqy[i], tv.idy, tv.fy)), fminf(fmaf(pqz[i], tv.idz, tv.fz), tv.best32));
+        hit[i] = c[i] != kNoChild4 && tmin[i] <= tmax * 1.000002f;
+        if (hit[i] && (near_c == kNoChild4 || tmin[i] < near_t)) {
+            near_c = (uint32_t)i;
+            near_t = tmin[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (hit[i] && (uint32_t)i != near_c) st.push(tv.sp, tmin[i], c[i]);
+    if (near_c != kNoChild4)
+        tv.cur = near_c == 0u ? c[0] : (near_c == 1u ? c[1] : (near_c == 2u ? c[2] : c[3]));
+    else
+        rtl::trav_pop(tv, st);
+}
+
 __device__ __forceinline__ void log_table_to_lds() { // rt_lds.h RT_LDS_LOG_TABLE_BYTES: rtl::log_cold reads it at the front
     for (uint32_t i = threadIdx.x; i < RT_LDS_LOG_TABLE_BYTES / 8u; i += (uint32_t)kBlock) reinterpret_cast<double *>(rt_lds)[i] = rtm_log_tab[i];
     __syncthreads();
@@ -93,9 +137,10 @@ __global__ __launch_bounds__(kBlock, 4) void begin_kernel(const RtLaunch L, cons
 // stage 2: persistent traversal with immediate refill from the global ray queue
 // stats (per launch, lane 0 of each wave): [0] node-block executions, [1] lanes at a node in them, [2] leaf-block executions,
 // [3] lanes at a leaf, [4] fetch executions, [5] lanes fetched
+template <bool WIDE4>
 __global__ __launch_bounds__(kBlock, 4) void traverse_kernel(const RtLaunch L, const ProbeRay *rays, const ProbeBegun *begun, uint32_t n, uint32_t total,
                                                              unsigned int *counter, ProbeHit *out, int fetch_min, int vote_leaf, int node_keep,
-                                                             unsigned long long *stats) {
+                                                             unsigned long long *stats, const RtNode4 *nodes4, uint32_t root4) {
     typedef RtRef16 Ref;
     log_table_to_lds();
     LdsStack16 st;
@@ -112,7 +157,7 @@ __global__ __launch_bounds__(kBlock, 4) void traverse_kernel(const RtLaunch L, c
     bool has = false, drained = false;
     unsigned long long s_nw = 0, s_nl = 0, s_lw = 0, s_ll = 0, s_fw = 0, s_fl = 0, prims = 0;
     const bool lane0 = (threadIdx.x & 63u) == 0u;
-    for (uint32_t trip = 0; trip < 0x40000000u; ++trip) { // (bounded: an experiment must not hang a box)
+    for (uint32_t trip = 0; trip < 0x4000000u; ++trip) { // (bounded: an experiment must not hang a box)
         const bool is_node = has && tv.cur < Ref::kLeaf;
         const bool is_leaf = has && tv.cur >= Ref::kLeaf && tv.cur < Ref::kDone;
         const bool is_free = !has || tv.cur == Ref::kDone;
@@ -165,7 +210,7 @@ __global__ __launch_bounds__(kBlock, 4) void traverse_kernel(const RtLaunch L, c
                     tv.best32 = rtl::up32(tv.best_t);
                     tv.r2a = rtl::world_roots_rcp(L, ps.o, rtl::dot(ps.d, ps.d));
                     tv.sp = 0;
-                    tv.cur = b.done ? (uint32_t)Ref::kDone : L.root;
+                    tv.cur = b.done ? (uint32_t)Ref::kDone : (WIDE4 ? root4 : L.root);
                     has = true;
                 } else {
                     drained = true;
@@ -188,7 +233,12 @@ __global__ __launch_bounds__(kBlock, 4) void traverse_kernel(const RtLaunch L, c
                 const bool at_node = has && tv.cur < Ref::kLeaf;
                 const int cnt = __popcll(__ballot(at_node));
                 if (cnt == 0) break;
-                if (at_node) rtl::trav_node_step<true>(L.nodes, tv, st);
+                if (at_node) {
+                    if (WIDE4)
+                        node4_step(nodes4, tv, st);
+                    else
+                        rtl::trav_node_step<true>(L.nodes, tv, st);
+                }
                 if (lane0) {
                     ++s_nw;
                     s_nl += (unsigned long long)cnt;
@@ -220,8 +270,46 @@ __global__ __launch_bounds__(kBlock, 4) void traverse_kernel(const RtLaunch L, c
 // rays: n records of 80 bytes {o[3], d[3], base, k, pad}; hits_out: n x {t, prim, pad}; ms_out: {begin_kernel, traverse_kernel} (best of
 // `repeats`); stats_out: 6 counters of the last traverse launch.  The scene must be committed on a device with a tree (no list mode)
 // and belong to the general + sphere media family.
+// the scene's binary tree collapsed into 4-wide nodes; returns the root's index and the deepest stack a walk can need
+static double area4(const rt::Aabb &b) {
+    const double dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+static uint32_t go4(const rt::FlatScene &f, int32_t node, std::vector<RtNode4> *out, int depth, int *deepest) { // (depth <= the binary tree's: 24)
+    struct Slot {
+        rt::Aabb box;
+        int32_t child; // >= 0 inner node of the binary tree, < 0 leaf (~prim)
+    };
+    std::vector<Slot> slots;
+    for (int c = 0; c < 2; ++c) slots.push_back(Slot{f.host_nodes[(size_t)node].box[c], f.host_nodes[(size_t)node].child[c]});
+    while (slots.size() < 4) {
+        int pick = -1;
+        for (size_t i = 0; i < slots.size(); ++i)
+            if (slots[i].child >= 0 && (pick < 0 || area4(slots[i].box) > area4(slots[(size_t)pick].box))) pick = (int)i;
+        if (pick < 0) break;
+        const rt::HostNode h = f.host_nodes[(size_t)slots[(size_t)pick].child];
+        slots[(size_t)pick] = Slot{h.box[0], h.child[0]};
+        slots.push_back(Slot{h.box[1], h.child[1]});
+    }
+    const uint32_t me = (uint32_t)out->size();
+    out->emplace_back();
+    *deepest = std::max(*deepest, depth + 1);
+    RtNode4 nd;
+    std::memset(&nd, 0, sizeof nd);
+    for (int i = 0; i < 4; ++i) nd.child[i] = kNoChild4;
+    for (size_t i = 0; i < slots.size(); ++i) {
+        float lo[3], hi[3];
+        rt::cull_box(slots[i].box, lo, hi);
+        nd.lo_x[i] = lo[0], nd.lo_y[i] = lo[1], nd.lo_z[i] = lo[2];
+        nd.hi_x[i] = hi[0], nd.hi_y[i] = hi[1], nd.hi_z[i] = hi[2];
+        nd.child[i] = slots[i].child >= 0 ? go4(f, slots[i].child, out, depth + 1, deepest) : (RT_REF_LEAF | (uint32_t)(~slots[i].child));
+    }
+    (*out)[me] = nd;
+    return me;
+}
+
 extern "C" int rt_probe_traverse(rt_scene *s, const void *rays_host, int n, int replicate, int fetch_min, int vote_leaf, int node_keep, int repeats, double *ms_out,
-                                 void *hits_out, unsigned long long *stats_out) {
+                                 void *hits_out, unsigned long long *stats_out, int wide4) {
     if (!s || !s->committed || s->device < 0 || n <= 0 || replicate < 1 || (long long)n * replicate > 0xFFFFFFF0ll) return -1;
     const uint32_t total = (uint32_t)n * (uint32_t)replicate;
     if (s->flat.n_list != 0 || s->flat.wide) return -2;
@@ -245,6 +333,21 @@ extern "C" int rt_probe_traverse(rt_scene *s, const void *rays_host, int n, int 
     L.world_mid = s->flat.world_mid ? 1 : 0;
     L.n_prims = s->flat.n_leaf_prims;
     L.max_depth = 100;
+    std::vector<RtNode4> nodes4;
+    int stack4 = 0;
+    uint32_t root4 = 0;
+    RtNode4 *d_nodes4 = nullptr;
+    if (wide4) {
+        if (s->flat.root >= RT_REF_LEAF) return -4; // (a single leaf: no tree)
+        root4 = go4(s->flat, (int32_t)s->flat.root, &nodes4, 0, &stack4);
+        stack4 = 3 * stack4 + 1;
+        if (nodes4.size() > RT_REF_MAX) return -4;
+        PROBE_TRY(hipMalloc((void **)&d_nodes4, nodes4.size() * sizeof(RtNode4)));
+        PROBE_TRY(hipMemcpy(d_nodes4, nodes4.data(), nodes4.size() * sizeof(RtNode4), hipMemcpyHostToDevice));
+        L.stack_entries = stack4;
+        ms_out[3] = (double)nodes4.size();
+        ms_out[4] = (double)stack4;
+    }
     const unsigned lds = RT_LDS_LOG_TABLE_BYTES + (unsigned)L.stack_entries * kBlock * 4u;
     ProbeRay *d_rays = nullptr;
     ProbeBegun *d_begun = nullptr;
@@ -262,7 +365,10 @@ extern "C" int rt_probe_traverse(rt_scene *s, const void *rays_host, int n, int 
     PROBE_TRY(hipGetDevice(&dev));
     PROBE_TRY(hipGetDeviceProperties(&prop, dev));
     int per_cu = 0;
-    PROBE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)traverse_kernel, kBlock, lds));
+    if (wide4)
+        PROBE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)traverse_kernel<true>, kBlock, lds));
+    else
+        PROBE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)traverse_kernel<false>, kBlock, lds));
     if (per_cu < 1) return -3;
     const int blocks = per_cu * prop.multiProcessorCount;
     hipEvent_t e0, e1;
@@ -280,8 +386,12 @@ extern "C" int rt_probe_traverse(rt_scene *s, const void *rays_host, int n, int 
         PROBE_TRY(hipMemset(d_counter, 0, 256));
         PROBE_TRY(hipMemset(d_stats, 0, 64));
         PROBE_TRY(hipEventRecord(e0, nullptr));
-        hipLaunchKernelGGL(traverse_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, nullptr, L, d_rays, d_begun, (uint32_t)n, total, d_counter, d_hits, fetch_min,
-                           vote_leaf, node_keep, d_stats);
+        if (wide4)
+            hipLaunchKernelGGL(traverse_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), lds, nullptr, L, d_rays, d_begun, (uint32_t)n, total, d_counter, d_hits,
+                               fetch_min, vote_leaf, node_keep, d_stats, d_nodes4, root4);
+        else
+            hipLaunchKernelGGL(traverse_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), lds, nullptr, L, d_rays, d_begun, (uint32_t)n, total, d_counter, d_hits,
+                               fetch_min, vote_leaf, node_keep, d_stats, d_nodes4, root4);
         PROBE_TRY(hipEventRecord(e1, nullptr));
         PROBE_TRY(hipEventSynchronize(e1));
         PROBE_TRY(hipEventElapsedTime(&ms, e0, e1));
@@ -298,5 +408,6 @@ extern "C" int rt_probe_traverse(rt_scene *s, const void *rays_host, int n, int 
     (void)hipFree(d_hits);
     (void)hipFree(d_counter);
     (void)hipFree(d_stats);
+    if (d_nodes4) (void)hipFree(d_nodes4);
     return 0;
 }

@@ -63,7 +63,7 @@ def main():
     sc, cam = scenes.build_product(scenes.cover(1, 1.0), device=0)
     lib = C.CDLL(os.environ["RT_MI355X_LIB"])
     lib.rt_probe_traverse.restype = C.c_int
-    lib.rt_probe_traverse.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_ulonglong)]
+    lib.rt_probe_traverse.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
     # the megakernel on the same image, for the same number of segments
     mk = []
     for _ in range(3):
@@ -86,14 +86,18 @@ def main():
     hits = np.zeros(n, dtype=[("t", "f8"), ("prim", "u4"), ("pad", "u4")])
     for name, order in (("path order (pixel-major, a path's segments adjacent)", np.arange(n)), ("mixed (random order)", order_mixed)):
         r = np.ascontiguousarray(rays[order])
-        for fetch_min, vote_leaf, node_keep in ((8, 16, 8), (16, 16, 8), (32, 16, 8), (48, 16, 8), (32, 32, 8), (32, 16, 16)):
-            ms = (C.c_double * 3)()
+        # PROBE_WIDE4=1: every setting with the scene's binary tree and with the same tree collapsed into 4-wide nodes (rt_probe.hip)
+        combos = [(f, v, k, 0) for f, v, k in ((8, 16, 8), (16, 16, 8), (32, 16, 8), (48, 16, 8), (32, 32, 8), (32, 16, 16))]
+        if os.environ.get("PROBE_WIDE4", "0") == "1":
+            combos = [(f, v, k, w) for f, v, k in ((16, 16, 8), (32, 16, 8), (32, 16, 16), (32, 12, 12)) for w in (0, 1)]
+        for fetch_min, vote_leaf, node_keep, wide4 in combos:
+            ms = (C.c_double * 5)()
             stats = (C.c_ulonglong * 6)()
-            rc = lib.rt_probe_traverse(sc._h, r.ctypes.data, n, REP, fetch_min, vote_leaf, node_keep, 2, ms, hits.ctypes.data, stats)
+            rc = lib.rt_probe_traverse(sc._h, r.ctypes.data, n, REP, fetch_min, vote_leaf, node_keep, 2, ms, hits.ctypes.data, stats, wide4)
             assert rc == 0, rc
             ok = np.array_equal(hits["t"], want_t[order]) and np.array_equal(hits["prim"].astype(np.float64), np.where(want_prim[order] > 4e9, 4294967295.0, want_prim[order]))
             st = [int(v) for v in stats]
-            run = {"order": name, "fetch_min": fetch_min, "vote_leaf": vote_leaf, "node_keep": node_keep, "begin_ms": ms[0], "traverse_ms": ms[1], "blocks": int(ms[2]),
+            run = {"order": name, "tree": "4-wide (%d nodes, stack %d)" % (int(ms[3]), int(ms[4])) if wide4 else "binary", "fetch_min": fetch_min, "vote_leaf": vote_leaf, "node_keep": node_keep, "begin_ms": ms[0], "traverse_ms": ms[1], "blocks": int(ms[2]),
                    "replicate": REP, "results_equal_the_lane_program": bool(ok), "ns_per_segment": {"begin": ms[0] * 1e6 / (n * REP), "traverse": ms[1] * 1e6 / max(1, min(int(stats[5]), n * REP))},
                    "rays_traversed": min(int(stats[5]), n * REP),
                    "node_block_occupancy": st[1] / max(1, 64 * st[0]), "leaf_block_occupancy": st[3] / max(1, 64 * st[2]),
@@ -102,7 +106,7 @@ def main():
             res["runs"].append(run)
     # the whole-render figures these stand against: 800 x 800 x 1000 spp = 2.25 G segments in ~302 ms
     (ROOT / "gpurun_out").mkdir(exist_ok=True)
-    json.dump(res, open(ROOT / "gpurun_out" / "wavefront_probe.json", "w"), indent=1)
+    json.dump(res, open(ROOT / "gpurun_out" / ("wide4_probe.json" if os.environ.get("PROBE_WIDE4", "0") == "1" else "wavefront_probe.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
