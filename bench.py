@@ -243,6 +243,13 @@ def main():
     from __graft_entry__ import load_package
     if a.same_device:
         local_rank = 0
+    # a launcher that shows every rank only its own GPU (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per process) leaves one device,
+    # index 0, whatever LOCAL_RANK says
+    n_visible = torch.cuda.device_count()
+    if n_visible < 1:
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    if local_rank >= n_visible:
+        local_rank %= n_visible
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     collective = world > 1 or a.collective_at_one
