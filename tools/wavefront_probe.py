@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """GPU box, one-off: the traversal-side stages of a WAVEFRONT organisation of the book-two cover scene, measured.
 ray-tracer_amd/csrc/rt_probe.hip (make -C ray-tracer_amd/csrc probe) holds the two kernels; the segments they work on are the real
-segments of the scene's paths, recorded by the CPU lane program (16 processes).  -> gpurun_out/wavefront_probe.json"""
+segments of the scene's paths, recorded by the CPU lane program (16 processes).  -> gpurun_out/wavefront_probe.json
+PROBE_WIDE4=1: the traverse stage over the scene's binary tree and over the same tree collapsed into 4-wide nodes, setting by
+setting (-> gpurun_out/wide4_probe.json); PROBE_FULL=0 skips the whole-config megakernel run; PROBE_EDGE / PROBE_SPP / PROBE_REPLICATE
+size the recording."""
 import ctypes as C
 import importlib
 import json
