@@ -458,7 +458,7 @@ def main():
         cfg_name = BASELINE_CONFIGS.get((a.scene, W, H, spp))
         scene_words = {"book_one": "book-one random-spheres", "cornell": "cornell-box", "cover": "book-two cover (main.rs)"}[a.scene]
         res = {
-            "metric": "Msamples/sec (pixels x spp), book-one 1200x800x500spp" if a.scene == "book_one" else f"Msamples/sec (pixels x spp), {a.scene}",
+            "metric": f"Msamples/sec (pixels x spp), book-one {W}x{H}x{spp}spp" if a.scene == "book_one" else f"Msamples/sec (pixels x spp), {a.scene} {W}x{H}x{spp}spp",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
