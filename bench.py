@@ -29,8 +29,10 @@ The JSON line carries
                 when the profile was taken with the loaded KERNELS (rt_version kernel hash) on this workload; otherwise null.
   cpu_baseline  the oracle in reference form on the host cores (count and CPU model stated), on a bounded sample of the same
                 workload, plus BASELINE configs[0] (400x225x50, depth 50) in full.
-With N > 1 every rank also reports render / gather / unpack / copy times of one extra, untimed step, and rank 0 checks the
-gathered image against a single-GPU render of the whole image.
+With N > 1 every rank also reports render / gather / unpack / copy times of one extra, untimed step.  For every N the line vouches
+for itself: rank 0 compares the image the last step left on the host with one plain render of the whole image on its GPU
+(image_matches_single_render; for N > 1 also image_matches_single_gpu) and, in the CPU-baseline leg, eight of its pixels with the
+oracle at the full sample count (oracle_pixels); a mismatch is in the line AND a non-zero exit code (3 / 4).
 """
 import argparse
 import importlib
@@ -71,8 +73,8 @@ def parse():
     ap.add_argument("--collective-at-one", action="store_true",
                     help="rehearsal on a one-GPU box: with ONE rank, still bring the communicator up (RCCL for --backend nccl) and send "
                          "the tiles through dist.gather, as the N > 1 path does")
-    ap.add_argument("--check", action="store_true", help="rank 0 also renders the whole image alone and compares (default for N > 1)")
-    ap.add_argument("--no-check", action="store_true", help="skip that comparison for N > 1")
+    ap.add_argument("--check", action="store_true", help="(the comparison with a plain render of the whole image is the default for every N since round 5; kept for old command lines)")
+    ap.add_argument("--no-check", action="store_true", help="skip the comparison of the last step's image with a plain render of the whole image")
     ap.add_argument("--ascending-tiles", action="store_true",
                     help="N > 1: hand every shard's tiles out in ascending order instead of the learnt deepest-first order (A/B)")
     ap.add_argument("--no-defer", action="store_true",
@@ -94,14 +96,28 @@ def cpu_model():
     return platform.processor() or platform.machine()
 
 
-def cpu_baseline(desc, name, W, H, spp_full, depth, seed, target_s, scenes=None):
+def cpu_baseline(desc, name, W, H, spp_full, depth, seed, target_s, scenes=None, image=None):
     """The oracle in reference form (recursive unpruned BVH, 4x4 per sprite, uv on every hit), threaded like the example
     drivers, on a bounded sample of the same workload; plus (book-one) BASELINE configs[0] -- 400x225, 50 spp, depth 50, the
-    reference's own CPU-runnable case -- in full."""
+    reference's own CPU-runnable case -- in full (SURVEY.md 8(d)).
+    image: the last image of the timed steps (host memory).  Eight of its pixels are rendered by the oracle at the FULL sample
+    count, in the kernels' iterative evaluation order, and must equal it bit for bit (`oracle_pixels`): the oracle as the checker
+    of the run that was just timed, after the timed region (VERDICT r4 #4)."""
     sys.path.insert(0, str(ROOT / "tests"))
+    import numpy as np
     import oracle_binding
     o = oracle_binding.build_oracle(desc)
     cores = os.cpu_count() or 1
+    checked = None
+    if image is not None:
+        rng = np.random.default_rng(12345)
+        pix = [(int(rng.integers(W)), int(rng.integers(H))) for _ in range(8)]
+        differing = []
+        for x, y in pix:
+            ref = o.render(W, H, spp_full, depth, seed, region=(x, y, x + 1, y + 1), iterative=True, nthreads=1)[y, x]
+            if not np.array_equal(ref, image[y, x]):
+                differing.append({"x": x, "y": y, "oracle": ref.tolist(), "gpu": image[y, x].tolist()})
+        checked = {"checked": len(pix), "differing": len(differing), "spp": spp_full, "pixels": pix, "mismatches": differing}
     t0 = time.perf_counter()
     o.render(W, H, 1, depth, seed, nthreads=cores)
     t1 = time.perf_counter() - t0
@@ -109,7 +125,7 @@ def cpu_baseline(desc, name, W, H, spp_full, depth, seed, target_s, scenes=None)
     t0 = time.perf_counter()
     o.render(W, H, spp, depth, seed, nthreads=cores)
     dt = time.perf_counter() - t0
-    out = {"value": W * H * spp / dt / 1e6, "unit": "Msamples/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
+    out = {"value": W * H * spp / dt / 1e6, "unit": "Msamples/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port", "oracle_pixels": checked,
            "sample": f"{name} {W}x{H} at {spp} spp (of {spp_full}), depth {depth}, whole image, {dt:.1f} s; "
                      f"oracle reference form, {cores} threads dealt rows y % n like examples/book-one.rs:56-65"}
     if scenes is not None and desc.name == "book-one":
@@ -218,6 +234,9 @@ def rank_environment():
     IPC; without it sharing device memory between processes (RCCL's peer-to-peer transport) fails with
     `hipIpcGetMemHandle: invalid argument`.  An operator's own setting wins."""
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # (what the rank really ran with goes into the line: config.rank_environment.  The failure without the variable is the pool's
+    # documented behaviour -- the task environment exports it on every box -- not something this repository has a log of.)
+    return {k: os.environ[k] for k in sorted(os.environ) if k.startswith(("HSA_", "NCCL_", "RCCL_", "HIP_VISIBLE", "ROCR_VISIBLE"))}
 
 
 def predicted_strong_scaling(n, ascending=False):
@@ -227,9 +246,12 @@ def predicted_strong_scaling(n, ascending=False):
     return ({1: 1.0, 2: 1.96, 4: 3.80, 8: 7.09} if ascending else {1: 1.0, 2: 1.97, 4: 3.86, 8: 7.23}).get(n)
 
 
+PREDICTION_KERNELS = "0b02c91c79c3db22"  # the kernel hash (rt_version) profiles/r04_shard_scaling*.log were measured with
+
+
 def main():
     a = parse()
-    rank_environment()
+    rank_env = rank_environment()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -249,7 +271,9 @@ def main():
     if n_visible < 1:
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
     if local_rank >= n_visible:
-        local_rank %= n_visible
+        if n_visible != 1:  # 1 < visible < ranks: folding would put several ranks on some GPUs silently
+            raise SystemExit(f"LOCAL_RANK {local_rank} but only {n_visible} devices are visible: one rank per GPU (or --same-device for a rehearsal)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     collective = world > 1 or a.collective_at_one
@@ -466,7 +490,7 @@ def main():
                        "scene_seed": a.scene_seed, "render_seed": a.seed, "n_prims": info["n_prims"],
                        "bvh_nodes": info["n_nodes"], "sharding": f"8x8 tiles, tile_id % {world}, one RCCL gather",
                        "collective": (f"dist.gather over {a.backend}" + (" (RCCL)" if a.backend == "nccl" else "") + f", {world} rank(s)") if collective else None,
-                       "library": rt.version(), "steps_pipelined_on_two_streams": bool(a.pipeline),
+                       "library": rt.version(), "rank_environment": rank_env, "steps_pipelined_on_two_streams": bool(a.pipeline),
                        "sums_behind_the_next_render": bool(defer),
                        "tile_order": {0: "ascending" + (" (a whole image always is)" if world == 1 else ""),
                                       1: "learnt from the warm-up's path lengths: deepest tiles first",
@@ -478,33 +502,45 @@ def main():
             "roofline": roof, "wall_s": dt, "last_kernel_ms": last_kernel_ms,
             "step_anatomy_ms": per_rank if per_rank is not None else [dict(anatomy, rank=0, device=local_rank, tiles=n_tiles[0])],
         }
-        image_ok = True
-        if (collective and not a.no_check) or a.check:
+        # The line vouches for itself: the image the LAST step left on the host (the untimed anatomy step: the same code path as the
+        # timed ones) against one plain rt_render of the whole image on this GPU -- for N > 1 that is the sharded image against a
+        # single-GPU one -- and, with the CPU baseline, eight of its pixels against the oracle at the full sample count.
+        image_ok = oracle_ok = True
+        last = host_images[(step_no[0] - 1) & 1].numpy().reshape(H, W, 3)
+        if not a.no_check:
             whole = sc.render(cam, W, H, spp, depth, a.seed)
-            last = host_images[(step_no[0] - 1) & 1]
-            image_ok = bool(np.array_equal(last.numpy().reshape(H, W, 3), whole))
-            res["image_matches_single_gpu"] = image_ok
+            image_ok = bool(np.array_equal(last, whole))
+            res["image_matches_single_render"] = image_ok
+            if collective or a.check:
+                res["image_matches_single_gpu"] = image_ok
         if per_rank is not None:
             # where the time of a step goes on each rank, and how even the shards are (the slowest rank is the step)
             rms = [r["render_ms"] for r in per_rank]
             res["ranks"] = {"render_ms": {"min": min(rms), "max": max(rms), "mean": sum(rms) / len(rms), "spread": max(rms) - min(rms)},
                             "gather_ms_rank0": per_rank[0].get("gather_ms"), "unpack_ms_rank0": per_rank[0].get("unpack_ms"),
                             "d2h_ms_rank0": per_rank[0].get("d2h_ms"),
-                            "predicted_speedup_over_1_gpu": predicted_strong_scaling(world, a.ascending_tiles),
-                            "prediction_source": "tools/shard_scaling.py: per-shard kernel times on one MI355X, before the gather"}
+                            # (a prediction made with other kernels than the loaded ones is not printed beside a measurement: ADVICE r4)
+                            "predicted_speedup_over_1_gpu": predicted_strong_scaling(world, a.ascending_tiles) if rt.kernel_hash() == PREDICTION_KERNELS else None,
+                            "prediction_source": f"tools/shard_scaling.py: per-shard kernel times on one MI355X, before the gather, kernels {PREDICTION_KERNELS}"
+                                                 + ("" if rt.kernel_hash() == PREDICTION_KERNELS else f" (loaded: {rt.kernel_hash()}: prediction withheld)")}
         if not a.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(desc, scene_words, W, H, spp, depth, a.seed, a.cpu_seconds, scenes)
+            res["cpu_baseline"] = cpu_baseline(desc, scene_words, W, H, spp, depth, a.seed, a.cpu_seconds, scenes, image=last)
+            res["oracle_pixels"] = {k: res["cpu_baseline"]["oracle_pixels"][k] for k in ("checked", "differing", "spp")}
+            oracle_ok = res["oracle_pixels"]["differing"] == 0
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
     else:
-        image_ok = True
+        image_ok = oracle_ok = True
     if collective:
         dist.barrier()
         dist.destroy_process_group()
     if not image_ok:  # the line above says so; the exit code does too (the launcher relays it)
-        print("[bench] the gathered image differs from a single-GPU render of the whole image", file=sys.stderr, flush=True)
+        print("[bench] the image of the last step differs from a plain single-GPU render of the whole image", file=sys.stderr, flush=True)
         raise SystemExit(3)
+    if not oracle_ok:
+        print("[bench] pixels of the timed image differ from the oracle at the full sample count (oracle_pixels in the line)", file=sys.stderr, flush=True)
+        raise SystemExit(4)
 
 
 if __name__ == "__main__":

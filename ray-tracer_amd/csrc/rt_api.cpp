@@ -27,7 +27,7 @@ extern "C" int rt_launch_render(const RtLaunch *L, unsigned features, int lens, 
 extern "C" int rt_launch_reduce(const double *samples, double *tiles, int n_owned_tiles, int s_count, int first_pass, int last_pass,
                                 int spp, int width, int height, int shard_index, int shard_count, int narrow_blocks,
                                 unsigned long long *tile_cost, void *stream);
-extern "C" int rt_launch_tile_order(const unsigned long long *tile_cost, int n, int levels, unsigned int *order, void *stream);
+extern "C" int rt_launch_tile_order(unsigned long long *tile_cost, int n, int levels, unsigned int *order, void *stream);
 extern "C" int rt_kernel_block_size(unsigned features);
 extern "C" int rt_kernel_waves_per_simd(unsigned features);
 extern "C" int rt_persistent_blocks(unsigned features, int lens, int count, int ldsnodes, unsigned lds_bytes, int *blocks_per_cu,
@@ -557,7 +557,7 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
                 if (to.d_order) HIP_TRY(hipFree(to.d_order));
                 to.d_cost = to.d_order = nullptr;
                 to.capacity = 0;
-                HIP_TRY(hipMalloc(&to.d_cost, (size_t)n_owned * sizeof(uint64_t)));
+                HIP_TRY(hipMalloc(&to.d_cost, ((size_t)n_owned + 1) * sizeof(uint64_t))); // + the largest cost (tile_top_kernel)
                 HIP_TRY(hipMalloc(&to.d_order, (size_t)n_owned * sizeof(uint32_t)));
                 to.capacity = n_owned;
             }
@@ -625,7 +625,7 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
                               learning ? (unsigned long long *)to.d_cost : nullptr, (void *)rs);
         if (rc != 0) return hip_fail((hipError_t)rc, "reduce_kernel launch");
         if (learning && pass == n_pass - 1) {
-            rc = rt_launch_tile_order((const unsigned long long *)to.d_cost, n_owned, order_levels, (unsigned int *)to.d_order, (void *)rs);
+            rc = rt_launch_tile_order((unsigned long long *)to.d_cost, n_owned, order_levels, (unsigned int *)to.d_order, (void *)rs);
             if (rc != 0) return hip_fail((hipError_t)rc, "tile_order_kernel launch");
             HIP_TRY(hipEventRecord(to.ready, rs));
             to.key = order_key;

@@ -960,7 +960,7 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
     const char *no_list = std::getenv("RT_NO_LIST");
     // (a scene with media inside media is always walked as a tree: its kernel family is compiled in that form only)
     if ((fs.feature_mask & RT_FEAT_GENERAL) && !(fs.feature_mask & RT_FEAT_MEDIUM_NESTED) && !fs.wide && n_bvh_leaves >= 2 && n_bvh_leaves <= RT_LIST_MAX &&
-        fs.n_leaf_prims <= 64 && // (a list kernel's stack entry has six bits for the leaf's prim index)
+        fs.n_leaf_prims <= (1 << RT_LIST_PRIM_BITS) && // (a list kernel's stack entry has that many bits for the leaf's prim index)
         !(no_list && *no_list == '1')) {
         fs.n_list = n_bvh_leaves;
         std::vector<float> packed((size_t)n_bvh_leaves * RT_LIST_BOX_FLOATS, 0.0f);

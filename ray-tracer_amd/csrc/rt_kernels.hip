@@ -185,7 +185,8 @@ struct LdsStackWide {
         *ref = e.y;
     }
 };
-// Box-LIST scenes (<= 24 leaves, prim indices below 64: rt_host.cpp): half a word per entry = ten bits of tnear (exponent + two
+// Box-LIST scenes (<= 24 leaves, prim indices below 1 << RT_LIST_PRIM_BITS = 64: rt_types.h, the gate in rt_host.cpp reads the same
+// constant): half a word per entry = ten bits of tnear (exponent + two
 // mantissa bits, rounded DOWN: a lower bound, as the 16-bit form's is; tnear >= 0, so the sign bit is not stored) | six of the
 // leaf's prim index.  Only the list step pushes and it pushes leaves only.  The 17 entries of the Cornell box are 8.5 KB per
 // 256-thread group instead of 17: room for queues of 60 entries beside the scene's records (rtl::rec_at<true>).
@@ -196,14 +197,14 @@ struct LdsStackList {
     uint16_t *base;
     __device__ __forceinline__ void set(unsigned char *lds) { base = reinterpret_cast<uint16_t *>(lds) + threadIdx.x; }
     __device__ __forceinline__ void push(int32_t &sp, float tnear, uint32_t ref) {
-        base[sp * BLOCK] = (uint16_t)(((__float_as_uint(tnear) >> 21) << 6) | (ref & 63u));
+        base[sp * BLOCK] = (uint16_t)(((__float_as_uint(tnear) >> 21) << RT_LIST_PRIM_BITS) | (ref & ((1u << RT_LIST_PRIM_BITS) - 1u)));
         ++sp;
     }
     __device__ __forceinline__ void pop(int32_t &sp, float *tnear, uint32_t *ref) {
         --sp;
         const uint32_t e = base[sp * BLOCK];
-        *tnear = __uint_as_float((e >> 6) << 21);
-        *ref = Ref::kLeaf | (e & 63u);
+        *tnear = __uint_as_float((e >> RT_LIST_PRIM_BITS) << 21);
+        *ref = Ref::kLeaf | (e & ((1u << RT_LIST_PRIM_BITS) - 1u));
     }
 };
 template <int BLOCK, bool WIDE, bool LIST>
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
 
     unsigned long long c_nodes = 0, c_prims = 0, c_segs = 0, c_draws = 0, c_samples = 0;
     unsigned long long c_nw = 0, c_nl = 0, c_lw = 0, c_ll = 0, c_sw = 0, c_sl = 0, c_id = 0, c_il = 0, c_ie = 0;
-    unsigned long long t_n = 0, t_l = 0, t_s = 0, t_fin = 0, t_ref = 0, t_beg = 0, t0 = 0, t1 = 0;
+    unsigned long long t_n = 0, t_l = 0, t_fin = 0, t_ref = 0, t_beg = 0, t0 = 0, t1 = 0;
     unsigned long long w_class = 0, w_new = 0, w_park = 0, w_pull = 0, w_busy = 0, w_scat = 0, w_off = 0, t_swap = 0; // swap diagnostics
 #define RT_STAMP(v) do { if (COUNT) v = __builtin_amdgcn_s_memtime(); } while (0)
     const bool counting_lane = COUNT && (threadIdx.x & 63) == 0;
@@ -878,22 +879,33 @@ __global__ void reduce_kernel(const double *samples, double *tiles, int n_owned_
 }
 
 // The hand-out order of a later render of the same view: owned tiles by descending cost (ties: ascending index), by counting --
-// thread i finds the rank of tile i among all n (n <= 65536 owned tiles: a few hundred microseconds, once per view).
+// thread i finds the rank of tile i among all n (n <= 65536 owned tiles, once per view).
 // levels > 0: the costs are compared in that many equal steps of the largest one, so that tiles of about the same depth keep their
 // ascending order (neighbouring tiles share the rays' neighbourhoods).
+// tile_top_kernel (one workgroup) leaves the largest cost in tile_cost[n]; tile_order_kernel then needs one division per TILE
+// (its own step) and compares the others against the step's two ends: the first form took the maximum and a 64-bit division per
+// PAIR in every thread (O(n^2) divisions, ~10 ms at n = 65536).
+__global__ void tile_top_kernel(unsigned long long *tile_cost, int n) {
+    __shared__ unsigned long long part[1024 / 64];
+    unsigned long long top = 0ull;
+    for (int j = (int)threadIdx.x; j < n; j += (int)blockDim.x) top = max(top, tile_cost[j]);
+    for (int off = 32; off > 0; off >>= 1) top = max(top, (unsigned long long)__shfl_xor((long long)top, off));
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = top;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        for (unsigned w = 1; w < blockDim.x / 64u; ++w) top = max(top, part[w]);
+        tile_cost[n] = top;
+    }
+}
 __global__ void tile_order_kernel(const unsigned long long *tile_cost, int n, int levels, unsigned int *order) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    unsigned long long top = 0ull;
-    if (levels > 0)
-        for (int j = 0; j < n; ++j) top = max(top, tile_cost[j]);
-    const unsigned long long step = levels > 0 ? top / (unsigned long long)levels + 1ull : 1ull;
-    auto key = [&](unsigned long long c) { return c / step; };
-    const unsigned long long mine = key(tile_cost[i]);
+    const unsigned long long step = levels > 0 ? tile_cost[n] / (unsigned long long)levels + 1ull : 1ull;
+    const unsigned long long lo = tile_cost[i] / step * step, hi = lo + step; // the costs of this tile's step: [lo, hi)
     unsigned int rank = 0u;
     for (int j = 0; j < n; ++j) {
-        const unsigned long long c = key(tile_cost[j]);
-        rank += (c > mine || (c == mine && j < i)) ? 1u : 0u;
+        const unsigned long long c = tile_cost[j];
+        rank += (c >= hi || (c >= lo && j < i)) ? 1u : 0u;
     }
     order[rank] = (unsigned int)i;
 }
@@ -1089,7 +1101,9 @@ extern "C" int rt_launch_reduce(const double *samples, double *tiles, int n_owne
     return e == hipSuccess ? 0 : (int)e;
 }
 
-extern "C" int rt_launch_tile_order(const unsigned long long *tile_cost, int n, int levels, unsigned int *order, void *stream) {
+// tile_cost: n sums of path lengths and one more word (the largest of them, written here)
+extern "C" int rt_launch_tile_order(unsigned long long *tile_cost, int n, int levels, unsigned int *order, void *stream) {
+    hipLaunchKernelGGL(tile_top_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, tile_cost, n);
     hipLaunchKernelGGL(tile_order_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tile_cost, n, levels, order);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

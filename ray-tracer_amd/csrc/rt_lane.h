@@ -591,6 +591,14 @@ RT_HD void chain_up_point(const RtLaunch &L, uint32_t first, uint32_t len, uint3
 // one of their answers.  For any other ray the boxes admit what the primitive accepts, so the gate only decides who pays.
 // near_axis: some component is zero or below 2^-30 of the largest (compared through the exponent fields; the rays in
 // question have components of exactly 0 or ~1e-17 of the others, a random direction qualifies once in ~1e9)
+// NOT covered (docs/parity.md section 4): the gate looks at the direction in the WORLD frame (the medium's frame inside a medium).
+// A ray that is axis-parallel only in the local frame of a rotated object -- its world direction has no small component, its
+// direction after M^-1 does -- still goes through the binary32 culling boxes above that object; the reference's boxes of the
+// levels BELOW the rotation see it as an in-plane ray.  No sweep has produced one (it needs a direction that cancels to ~1e-17
+// through a general matrix); it would show as a pixel on which the oracle's own trees disagree, like the nine of round 4.
+// Cost of the class where it does fire (trav_begin): one binary64 test per leaf prim and segment in ONE lane -- n_prims x the
+// path's remaining segments; nothing in an ordinary scene, and in a wide scene (41 000 prims) an edge-running path of 100
+// segments is 4 M tests = a few ms of one wave, bounded by max_depth.
 RT_HD bool near_axis(V3 d) {
     const uint32_t ex = RT_HI32(d.x) & 0x7FFFFFFFu, ey = RT_HI32(d.y) & 0x7FFFFFFFu, ez = RT_HI32(d.z) & 0x7FFFFFFFu;
     return umin(umin(ex, ey), ez) + (30u << 20) <= umax(umax(ex, ey), ez);
@@ -946,8 +954,10 @@ RT_HD bool trav_ray_constants(const RtLaunch &L, V3 o, V3 d, Trav &tv) {
     tv.idz = rcp32((float)d.z);
     bool near_plane = false;
     const float big = fmaxf(fmaxf(fabsf(tv.idx), fabsf(tv.idy)), fabsf(tv.idz)), small = fminf(fminf(fabsf(tv.idx), fabsf(tv.idy)), fabsf(tv.idz));
-    if (__builtin_expect(!(big <= fminf(small * 0x1p29f, 0x1p60f)), 0)) { // (hardly ever; a NaN direction comes here too)
-        near_plane = !(big <= small * 0x1p29f);
+    if (__builtin_expect(!(big <= fminf(small * 0x1p29f, 0x1p60f)), 0)) { // (hardly ever; a direction of three NaNs comes here too)
+        // a direction with a NaN component hits nothing on either way (every primitive test compares false); it takes the ordinary
+        // walk, whose slabs drop a NaN axis, instead of the scan over all prims below (41 000 tests per segment in a wide scene)
+        near_plane = !(big <= small * 0x1p29f) && d.x == d.x && d.y == d.y && d.z == d.z;
         if (fabsf(tv.idx) > 0x1p60f) tv.idx = copysignf(__builtin_huge_valf(), tv.idx);
         if (fabsf(tv.idy) > 0x1p60f) tv.idy = copysignf(__builtin_huge_valf(), tv.idy);
         if (fabsf(tv.idz) > 0x1p60f) tv.idz = copysignf(__builtin_huge_valf(), tv.idz);
@@ -1159,7 +1169,7 @@ RT_HD V3 texture_value(const RtLaunch &L, uint32_t tex, double u, double v) {
 
 // Dielectric::schlickReflectionProbability(theta = acos(c), n1, n2) (src/material.rs:140-143)
 // evaluated from c directly: powf(2) -> q*q, cos(acos(c)) -> c, powf(5) by multiplication.  Each substitution moves the
-// probability by a few ulp at most, and the value is only ever compared with a uniform draw: in 200 M random (c, index, draw)
+// probability by a few ulp at most, and the value is only ever compared with a uniform draw: in 20 M random (c, index, draw)
 // triples the decision never differs from the reference's own evaluation with the host libm's acos / cos / pow
 // (tests/test_libm_cpu.py::test_schlick_by_multiplication_decides_like_the_reference); deviation (ii) of docs/parity.md.
 // (The reference's evaluation, restated bit for bit, exists -- rtm::acos / cos / pow -- and a draw within 1e-9 of the threshold

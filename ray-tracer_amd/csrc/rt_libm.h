@@ -16,6 +16,21 @@
 //
 // Not reproduced: errno, floating-point exception flags, and the sign / payload of a NaN result (x86 and gfx950 produce
 // different default NaNs); a NaN comes back wherever glibc returns one.
+// ---------------------------------------------------------------------------------------------------------------------------
+// LICENCE OF THIS FILE.  This file is a derived work of the GNU C Library 2.35 (sysdeps/ieee754/dbl-64/: e_log.c, e_pow.c,
+// e_exp_data.c / e_pow_log_data.c / e_log_data.c, s_sin.c, dosincos.c, sincostab.c, e_asin.c, e_atan2.c, s_atan.c and their
+// headers), whose algorithms it restates and whose tables it carries:
+//   Copyright (C) 1996-2022 Free Software Foundation, Inc.
+//   e_log.c, e_pow.c and their data: derived from the ARM Optimized Routines, Copyright (c) 2018, Arm Limited (contributed to
+//     glibc under the LGPL; upstream dual-licensed MIT OR Apache-2.0 WITH LLVM-exception).
+//   s_sin.c, e_asin.c, e_atan2.c, s_atan.c and their tables: IBM Accurate Mathematical Library, written by International
+//     Business Machines Corp., Copyright (C) 2001-2022 Free Software Foundation, Inc.
+// The GNU C Library is free software; you can redistribute it and/or modify it under the terms of the GNU Lesser General Public
+// License as published by the Free Software Foundation; either version 2.1 of the License, or (at your option) any later
+// version.  It is distributed in the hope that it will be useful, but WITHOUT ANY WARRANTY; without even the implied warranty
+// of MERCHANTABILITY or FITNESS FOR A PARTICULAR PURPOSE.  See the GNU Lesser General Public License for more details
+// (LICENSES/LGPL-2.1.txt at the root of this repository; NOTICE there says what that means for librt_mi355x.so).
+// ---------------------------------------------------------------------------------------------------------------------------
 #ifndef RT_LIBM_H
 #define RT_LIBM_H
 

@@ -11,11 +11,13 @@
 #define RT_STACK_DEPTH 24   /* traversal stack entries per lane; the builder bounds the tree depth to this */
 #define RT_MAX_HOISTED 4    /* scene-filling prims tested up front instead of through the BVH */
 #define RT_LIST_MAX 24      /* general scenes of up to this many BVH leaves are walked as a box LIST (rtl::trav_list_step) */
+#define RT_LIST_PRIM_BITS 6  /* bits of a LIST kernel's half-word stack entry that hold the leaf's prim index (rt_kernels.hip LdsStackList): a LIST scene has at most 1 << 6 leaf prims, hoisted ones included */
 #define RT_LIST_SCENE_MAX 12288 /* a LIST scene whose records (transforms, prims, materials) fit this many bytes AND the workgroup's LDS share keeps them in LDS */
 #ifndef RT_LIST_LDS_ARRAYS
 #define RT_LIST_LDS_ARRAYS 0x1F /* which of them are READ there: 1 xforms, 2 prim_geo, 4 prim_meta, 8 prim_extra, 16 materials (A/B knob) */
 #endif
 #define RT_LIST_BOX_FLOATS 9 /* one list box: {lo, hi, lo} per axis -- entry plane at [s], exit plane at [s + 1], s = sign bit of 1/d */
+static_assert((1 << RT_LIST_PRIM_BITS) >= RT_LIST_MAX + RT_MAX_HOISTED, "every leaf of a LIST scene needs an index that fits the stack entry");
 #define RT_MAX_CHAIN 4      /* transform levels above one leaf (Sprite > BVH > Sprite > TransformedGeometry ...) every kernel family unrolls */
 #define RT_MAX_CHAIN_DEEP 15 /* levels the family for general media / deep chains walks (the ones beyond RT_MAX_CHAIN in a run-time loop) */
 #define RT_MAX_MEDIUM_NESTING 3 /* ConstantMedium levels inside one another (a medium in the boundary of a medium in ...) */

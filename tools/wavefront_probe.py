@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU box, one-off: the traversal-side stages of a WAVEFRONT organisation of the book-two cover scene, measured.
-ray-tracer_amd/csrc/rt_probe.hip (make -C ray-tracer_amd/csrc probe) holds the two kernels; the segments they work on are the real
+tools/probe/rt_probe.hip (make -C tools/probe) holds the two kernels; the segments they work on are the real
 segments of the scene's paths, recorded by the CPU lane program (16 processes).  -> gpurun_out/wavefront_probe.json
 PROBE_WIDE4=1: the traverse stage over the scene's binary tree and over the same tree collapsed into 4-wide nodes, setting by
 setting (-> gpurun_out/wide4_probe.json); PROBE_FULL=0 skips the whole-config megakernel run; PROBE_EDGE / PROBE_SPP / PROBE_REPLICATE
@@ -43,7 +43,7 @@ def record(band):
 
 
 def main():
-    os.environ["RT_MI355X_LIB"] = str(ROOT / "ray-tracer_amd" / "lib" / "librt_mi355x_travprobe.so")
+    os.environ["RT_MI355X_LIB"] = str(ROOT / "tools" / "probe" / "_build" / "librt_mi355x_travprobe.so")
     t0 = time.time()
     procs = 16
     bands = [(H * i // procs, H * (i + 1) // procs) for i in range(procs)]
