@@ -1,93 +1,76 @@
-// examples/book-one.rs of the reference with the sampling loop moved to the MI355X.
-// Scene construction keeps the reference's structure (examples/book-one.rs:103-205); the
-// unseedable thread_rng() is replaced by any seeded generator of the caller's choice
-// (a tiny SplitMix64 here -- this driver is NOT the pinned scene of the test-suite, which
-// uses include/rt_rng.h through the C++ / Python drivers).
-use ray_tracer_mi355x::*;
+// The random-spheres scene of "Ray Tracing in One Weekend" (the reference's examples/book-one.rs) on the MI355X, written
+// against this crate's copy of the reference's API.  Scene data -- sizes, colours, the order of the random draws -- follow
+// examples/book-one.rs:103-205, so that with SCENE_SEED = 1 this is the scene the C++ and Python drivers of the repository render
+// (scenes.book_one(1)); the code around the data is this example's own (README.md has the three-edit recipe that turns the
+// reference's own file into a driver of this crate instead).
+extern crate ray_tracer;
+
+use ray_tracer::camera::PerspectiveCamera;
+use ray_tracer::geometry::Sphere;
+use ray_tracer::mat4::Mat4;
+use ray_tracer::material::{Dielectric, DiffuseLight, Lambertian, Material, Metal};
+use ray_tracer::optimize::{AxisAlignedBoundingBox, Bound, BoundingVolumeHierarchyNode};
+use ray_tracer::sprite::Sprite;
+use ray_tracer::util::{write_ppm, HostRng};
+use ray_tracer::vec3::Vec3;
+
 use std::sync::Arc;
 
-struct SplitMix64(u64);
-impl SplitMix64 {
-    fn next_f64(&mut self) -> f64 {
-        self.0 = self.0.wrapping_add(0x9E3779B97F4A7C15);
-        let mut z = self.0;
-        z = (z ^ (z >> 30)).wrapping_mul(0xBF58476D1CE4E5B9);
-        z = (z ^ (z >> 27)).wrapping_mul(0x94D049BB133111EB);
-        ((z ^ (z >> 31)) >> 11) as f64 * (1.0 / 9007199254740992.0)
-    }
-    fn gen_range(&mut self, lo: f64, hi: f64) -> f64 {
-        lo + (hi - lo) * self.next_f64()
-    }
+type Object = Arc<dyn Bound<AxisAlignedBoundingBox>>;
+
+const SCENE_SEED: u64 = 1;
+const RENDER_SEED: u64 = 1;
+
+/// a sphere of `radius` at `at`: `Sprite<Sphere, U>` behind the list's trait object
+fn ball<U: Material + 'static>(radius: f64, material: U, at: Vec3) -> Object {
+    Arc::new(Sprite::builder().geometry(Sphere::new(radius).into()).material(Arc::new(material)).transform(Mat4::translation(at)).build())
 }
 
-fn translation(t: Vec3) -> Mat4 {
-    let mut m = [0.0; 16];
-    m[0] = 1.0;
-    m[5] = 1.0;
-    m[10] = 1.0;
-    m[15] = 1.0;
-    m[12] = t.x;
-    m[13] = t.y;
-    m[14] = t.z;
-    m
-}
-
-fn random_scene(seed: u64) -> Vec<Sprite> {
-    let mut g = SplitMix64(seed);
-    let small = Arc::new(Geometry::Sphere(0.2));
-    let big = Arc::new(Geometry::Sphere(1.0));
-    let mut scene = vec![
-        Sprite::builder()
-            .geometry(Arc::new(Geometry::Sphere(1000.0)))
-            .material(Arc::new(Material::Lambertian(Vec3::new(0.5, 0.5, 0.5).into())))
-            .transform(translation(Vec3::new(0.0, -1000.0, 0.0)))
-            .build(),
-        Sprite::builder()
-            .geometry(Arc::new(Geometry::Sphere(2000.0)))
-            .material(Arc::new(Material::DiffuseLight(Vec3::new(0.5, 0.7, 1.0).into())))
-            .build(),
-    ];
+fn random_scene(seed: u64) -> Vec<Object> {
+    let mut generator = HostRng::new(seed);
+    let mut scene: Vec<Object> = Vec::new();
+    // the ground is a sphere of radius 1000 below the origin; the sky is an emitting sphere around everything (no transform)
+    scene.push(ball(1000.0, Lambertian::new(Vec3::new(0.5, 0.5, 0.5)), Vec3::new(0.0, -1000.0, 0.0)));
+    scene.push(Arc::new(Sprite::builder().geometry(Sphere::new(2000.0).into()).material(DiffuseLight::new(Vec3::new(0.5, 0.7, 1.0)).into()).build()));
     for a in -11..11 {
         for b in -11..11 {
-            let which = g.gen_range(0.0, 1.0);
-            let center = Vec3::new(a as f64 + 0.9 * g.gen_range(0.0, 1.0), 0.2, b as f64 + 0.9 * g.gen_range(0.0, 1.0));
-            let (dx, dz) = (center.x - 4.0, center.z);
-            if (dx * dx + dz * dz).sqrt() > 0.9 {
-                let material = if which < 0.3 {
-                    let (r, gr, bl) = (g.gen_range(0.0, 1.0), g.gen_range(0.0, 1.0), g.gen_range(0.0, 1.0));
-                    Material::Lambertian(Vec3::new(r * r, gr * gr, bl * bl).into())
-                } else if which < 0.6 {
-                    let albedo = Vec3::new(g.gen_range(0.5, 1.0), g.gen_range(0.5, 1.0), g.gen_range(0.5, 1.0));
-                    Material::Metal(albedo.into(), g.gen_range(0.0, 0.5))
-                } else {
-                    Material::Dielectric(1.5)
-                };
-                scene.push(Sprite::builder().geometry(small.clone()).material(Arc::new(material)).transform(translation(center)).build());
+            let which = generator.gen_range(0.0, 1.0);
+            let center = Vec3::new(a as f64 + 0.9 * generator.gen_range(0.0, 1.0), 0.2, b as f64 + 0.9 * generator.gen_range(0.0, 1.0));
+            if (center - Vec3::new(4.0, 0.2, 0.0)).length() <= 0.9 {
+                continue; // too close to the big metal sphere
+            }
+            if which < 0.3 {
+                let c = Vec3::new(generator.gen_range(0.0, 1.0), generator.gen_range(0.0, 1.0), generator.gen_range(0.0, 1.0));
+                scene.push(ball(0.2, Lambertian::new(c * c), center));
+            } else if which < 0.6 {
+                let c = Vec3::new(generator.gen_range(0.5, 1.0), generator.gen_range(0.5, 1.0), generator.gen_range(0.5, 1.0));
+                let fuzziness = generator.gen_range(0.0, 0.5);
+                scene.push(ball(0.2, Metal::new(c, fuzziness), center));
+            } else {
+                scene.push(ball(0.2, Dielectric::new(1.5), center));
             }
         }
     }
-    scene.push(Sprite::builder().geometry(big.clone()).material(Arc::new(Material::Lambertian(Vec3::new(0.4, 0.2, 0.1).into())))
-        .transform(translation(Vec3::new(-4.0, 1.0, 0.0))).build());
-    scene.push(Sprite::builder().geometry(big.clone()).material(Arc::new(Material::Metal(Vec3::new(0.7, 0.6, 0.5).into(), 0.0)))
-        .transform(translation(Vec3::new(4.0, 1.0, 0.0))).build());
-    scene.push(Sprite::builder().geometry(big).material(Arc::new(Material::Dielectric(1.5)))
-        .transform(translation(Vec3::new(0.0, 1.0, 0.0))).build());
+    scene.push(ball(1.0, Lambertian::new(Vec3::new(0.4, 0.2, 0.1)), Vec3::new(-4.0, 1.0, 0.0)));
+    scene.push(ball(1.0, Metal::new(Vec3::new(0.7, 0.6, 0.5), 0.0), Vec3::new(4.0, 1.0, 0.0)));
+    scene.push(ball(1.0, Dielectric::new(1.5), Vec3::new(0.0, 1.0, 0.0)));
     scene
 }
 
 fn main() {
-    let (width, height) = (1600usize, 800usize);
-    let world = BoundingVolumeHierarchyNode::new(&random_scene(1), 0).unwrap().unwrap();
+    // BASELINE configs[1]: 1200 x 800, 500 samples per pixel, depth 100
+    let (width, height, samples, depth) = (1200usize, 800usize, 500usize, 100usize);
+    let world = BoundingVolumeHierarchyNode::new(random_scene(SCENE_SEED)).unwrap();
     let camera = PerspectiveCamera::new(
         Vec3::new(13.0, 2.0, 3.0),
         Vec3::new(0.0, 0.0, 0.0),
         Vec3::new(0.0, 1.0, 0.0),
-        (20.0f64).to_radians(),
+        20.0_f64.to_radians(),
         width as f64 / height as f64,
         10.0,
         0.05,
     );
-    // was: cpuCount threads, rows y % cpuCount, 100 x color(&ray, world, 100) per pixel, mpsc channel
-    let buffer = world.render(&camera, width, height, 100, 100, 1).unwrap();
-    write_ppm("/dev/stdout", &buffer, width, height).unwrap();
+    // the reference's worker threads, its `color(&ray, world, 100)` per sample and its mpsc fan-in (examples/book-one.rs:50-88)
+    let buffer = world.render(&camera, width, height, samples, depth, RENDER_SEED).unwrap();
+    write_ppm("/dev/stdout", &buffer).unwrap(); // the P3 text of examples/book-one.rs:28-30,90-100
 }

@@ -9,7 +9,7 @@ pub struct rt_scene {
 }
 
 #[repr(C)]
-#[derive(Clone, Copy, Default)]
+#[derive(Clone, Copy, Debug, Default)]
 pub struct rt_camera {
     pub eye: [c_double; 3],
     pub lower_left: [c_double; 3],
@@ -19,7 +19,7 @@ pub struct rt_camera {
 }
 
 #[repr(C)]
-#[derive(Clone, Copy)]
+#[derive(Clone, Copy, Debug)]
 pub struct rt_render_params {
     pub width: c_int,
     pub height: c_int,
