@@ -309,6 +309,10 @@ int rt_scene_copy_nodes(const rt_scene *, double *out, int max_nodes);
 int rt_scene_hash(const rt_scene *, uint64_t *out);
 /* world-space AABB of prim i: {lo[3], hi[3]} */
 int rt_scene_prim_bounds(const rt_scene *, int prim, double out[6]);
+/* leaves of the acceleration structure: 1 = prim i is a leaf of its own; 6 = prim i is the head of a CUBE GROUP, one leaf that stands
+ * for prims i .. i + 5, the six faces of one Cube::new (src/geometry.rs:254-286) whose culling boxes are the sides of one box (the
+ * 400 floor boxes of examples/main.rs:161-201); 0 = prim i is one of the other five faces of a group */
+int rt_scene_prim_group(const rt_scene *, int prim);
 
 /* ---- device self-test used by the GPU parity tests: evaluates sqrt, div on the
  *      device for n inputs so the host can check they are correctly rounded ---- */

@@ -143,6 +143,7 @@ ABI = {
     "rt_scene_copy_nodes": (C.c_int, [_VP, _DP, C.c_int]),
     "rt_scene_hash": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     "rt_scene_prim_bounds": (C.c_int, [_VP, C.c_int, _DP]),
+    "rt_scene_prim_group": (C.c_int, [_VP, C.c_int]),
     "rt_probe_device_math": (C.c_int, [C.c_int, _DP, _DP, C.c_int, _DP, _DP]),
     "rt_probe_device_libm": (C.c_int, [C.c_int, C.c_int, _DP, _DP, C.c_int, _DP]),
 }
@@ -366,6 +367,10 @@ class Scene:
         out = np.zeros(6)
         _check(lib().rt_scene_prim_bounds(self._h, i, _dp(out)))
         return out
+
+    def prim_group(self, i) -> int:
+        """1: prim i is a leaf of its own; 6: the head of a cube group (one leaf for prims i .. i + 5); 0: another face of a group"""
+        return _check(lib().rt_scene_prim_group(self._h, i))
 
     # rendering
     def render(self, cam: "Camera", width, height, spp, max_depth, seed=1, shard=(0, 1), counters=False):

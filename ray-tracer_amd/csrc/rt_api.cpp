@@ -249,6 +249,7 @@ int rt_scene_commit(rt_scene *s, int device) {
         s->device = device;
         size_t total = 0;
         if ((rc = upload(s->flat.nodes, &s->d_nodes, &total))) return rc;
+        if ((rc = upload(s->flat.nodes_half, &s->d_nodes_half, &total))) return rc; // the tree with binary16 planes, for an LDS copy
         if ((rc = upload(s->flat.prim_meta, &s->d_prim_meta, &total))) return rc;
         if ((rc = upload(s->flat.prim_geo, &s->d_prim_geo, &total))) return rc;
         if ((rc = upload(s->flat.prim_extra, &s->d_prim_extra, &total))) return rc;
@@ -483,9 +484,20 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
         if (RT_LIST_LDS_ARRAYS & 8) L.prim_extra = (const RtPrimExtra *)(uintptr_t)(table + off[3]);
         if (RT_LIST_LDS_ARRAYS & 16) L.materials = (const RtMaterial *)(uintptr_t)(table + off[4]);
     }
-    const int ldsnodes = list || (!wide && node_bytes > 0 && !(no_lds && *no_lds == '1') &&
-                                  rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, node_bytes, min_cap, front).total <= lds_share);
-    const unsigned in_lds = ldsnodes ? node_bytes : 0u;
+    int ldsnodes = list || (!wide && node_bytes > 0 && !(no_lds && *no_lds == '1') &&
+                            rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, node_bytes, min_cap, front).total <= lds_share);
+    // the binary32 nodes do not fit: the same tree with binary16 planes (RtNodeH, half the bytes) may -- the family with sphere media /
+    // textures has kernels for it (the book-two cover: 1406 nodes over cube groups, 45 KB beside a 56 KB stack).  RT_NO_HALF_NODES=1: never.
+    const char *no_half = std::getenv("RT_NO_HALF_NODES");
+    const unsigned half_bytes = (unsigned)(s->flat.nodes_half.size() * sizeof(RtNodeH));
+    const int half = !ldsnodes && !list && !wide && swap && half_bytes > 0 && (feat & ~1u) != 0u && !(feat & (8u | 16u)) && !(no_lds && *no_lds == '1') &&
+                     !(no_half && *no_half == '1') && s->d_nodes_half &&
+                     rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, half_bytes, min_cap, front).total <= lds_share;
+    if (half) {
+        ldsnodes = 1;
+        L.nodes = (const RtNode *)s->d_nodes_half; // RtNodeH records: the kernel's HALF instantiation reads them as such
+    }
+    const unsigned in_lds = ldsnodes ? (half ? half_bytes : node_bytes) : 0u;
     const unsigned swap_cap = swap ? rt_swap_cap_that_fits((unsigned)L.stack_entries, block, entry_bytes, in_lds, groups_per_cu, front) : 0u;
     L.swap_cap = (int)swap_cap;
     const RtLdsLayout lay = rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, in_lds, swap ? rt_swap_cap_effective(block, swap_cap) : 0u, front);
@@ -497,7 +509,7 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     if (const char *t = std::getenv("RT_TEST_LDS_SHORT")) // claim fewer bytes than the layout needs -> the kernel must refuse
         if (*t == '1') L.lds_bytes = lds_bytes - 64u;
 #endif
-    const int lds_mode = (ldsnodes ? 1 : 0) | (swap ? 2 : 0) | (wide ? 4 : 0) | (list ? 8 : 0) | (reclds ? 16 : 0);
+    const int lds_mode = (ldsnodes ? 1 : 0) | (swap ? 2 : 0) | (wide ? 4 : 0) | (list ? 8 : 0) | (reclds ? 16 : 0) | (half ? 32 : 0);
     int per_cu = 0, n_cu = 0, rc = 0;
     const unsigned occ_key = feat | (lens ? 32u : 0u) | (count ? 64u : 0u) | ((unsigned)lds_mode << 7); // feat uses bits 0-4
     if (s->occ_key == occ_key && s->occ_lds == lds_bytes) {
@@ -651,7 +663,7 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     lc.n_jobs = L.n_jobs;
     lc.job_spp = L.job_spp;
     lc.kernel_features = feat;
-    lc.lds_nodes = ldsnodes;
+    lc.lds_nodes = ldsnodes ? (half ? 2 : 1) : 0; // 2: as RtNodeH (binary16 planes)
     lc.swap = swap;
     lc.workspace_bytes = need;
     lc.swap_cap = (int)swap_cap;
@@ -1098,6 +1110,13 @@ int rt_scene_prim_bounds(const rt_scene *s, int prim, double out[6]) {
         out[3 + i] = b.hi[i];
     }
     return RT_OK;
+}
+
+int rt_scene_prim_group(const rt_scene *s, int prim) {
+    if (!s) return fail(RT_ERR_INVALID, "null argument");
+    if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
+    if (prim < 0 || prim >= s->flat.n_leaf_prims) return fail(RT_ERR_INVALID, "prim out of range");
+    return (size_t)prim < s->flat.group_len.size() ? s->flat.group_len[(size_t)prim] : 1;
 }
 
 int rt_probe_device_math(int device, const double *a, const double *b, int n, double *out_sqrt, double *out_div) {

@@ -376,6 +376,7 @@ struct Leaf {
     std::vector<Link> chain;
     std::vector<Shape> boundary; // RT_PRIM_MEDIUM_C
     bool unbounded = false;      // hits may lie anywhere on the ray, not only inside `bound` (a medium over an open boundary)
+    int cube = -1, face = 0;     // face `face` of the cube-th GEO_CUBE expansion (all six faces emitted), else -1
 };
 
 // the shape's bound carried through every level of `outer` + `inner` (outermost first): the AABB of the 8 transformed
@@ -423,6 +424,7 @@ struct Flattener {
     const SceneIR &ir;
     FlatScene &fs;
     std::vector<Leaf> leaves;
+    int n_cubes = 0;
     uint32_t medium_slots = 0;
     std::string error;
     int rc = RT_OK;
@@ -621,6 +623,9 @@ struct Flattener {
         case GEO_CUBE: {
             std::vector<Shape> shapes;
             if (!collect_shapes(gi, chain, &shapes, depth)) return false;
+            // the six faces of one Cube::new, in order (a face with a singular matrix is dropped by collect_shapes: no group then)
+            const int cube = (g.kind == GEO_CUBE && shapes.size() == 6) ? n_cubes++ : -1;
+            int face = 0;
             for (const Shape &sh : shapes) {
                 if (sh.chain.size() > RT_MAX_CHAIN_DEEP)
                     return fail(RT_ERR_UNSUPPORTED, "more than RT_MAX_CHAIN_DEEP (15) transform levels above one primitive");
@@ -646,6 +651,8 @@ struct Flattener {
                 }
                 lf.bound = chain_bound(shape_local_bound(sh), sh.chain, {});
                 pad(&lf.bound);
+                lf.cube = cube;
+                lf.face = face++;
                 leaves.push_back(std::move(lf));
             }
             return true;
@@ -920,9 +927,114 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
         if ((lf.meta.kind & 0xFFu) == RT_PRIM_MEDIUM_C) emit_boundary(k, lf.boundary);
     }
 
-    // BVH over the non-hoisted leaves
+    // Cube groups (RT_META_GROUP_BIT, RtCubeGroup): the six faces of one Cube::new become ONE leaf of the tree when their culling boxes
+    // are the six sides of one box -- a cube whose sprite chain keeps it axis-aligned: the 400 floor boxes of examples/main.rs:161-201
+    // are 2400 of the cover's 3400 leaves.  The leaf step derives the faces' boxes from twelve planes (rtl::trav_leaf_step); each
+    // derived box is checked here, plane by plane, to CONTAIN the face's own binary32 culling box.  Only for the kernel families whose
+    // leaf step knows groups (rtl::CubeGroups: general prims, tree walk, 16-bit references, no media over general boundaries), never in a
+    // scene small enough for the box list.  RT_NO_CUBE_GROUPS=1: every face a leaf of its own (A/B runs).
+    std::vector<int> group_len((size_t)fs.n_leaf_prims, 1); // 6 at the head of a group, 0 at its other five prims
+    {
+        const char *no_groups = std::getenv("RT_NO_CUBE_GROUPS");
+        const char *no_list_env = std::getenv("RT_NO_LIST");
+        const int n_bvh = fs.n_leaf_prims - fs.n_hoisted;
+        const bool list_scene = (fs.feature_mask & RT_FEAT_GENERAL) && !(fs.feature_mask & RT_FEAT_MEDIUM_NESTED) && n_bvh >= 2 && n_bvh <= RT_LIST_MAX &&
+                                fs.n_leaf_prims <= (1 << RT_LIST_PRIM_BITS) && !(no_list_env && *no_list_env == '1');
+        const bool family_ok = (fs.feature_mask & RT_FEAT_GENERAL) &&
+                               !(fs.feature_mask & (RT_FEAT_MEDIUM_GENERAL | RT_FEAT_DEEP_CHAIN | RT_FEAT_MEDIUM_NESTED)) &&
+                               (size_t)fs.n_leaf_prims <= RT_REF_MAX;
+        if (family_ok && !list_scene && !(no_groups && *no_groups == '1')) {
+            for (int k = fs.n_hoisted; k + 6 <= fs.n_leaf_prims; ++k) {
+                const Leaf &h = leaves[final_order[(size_t)k]];
+                if (h.cube < 0 || h.face != 0) continue;
+                bool six = true;
+                for (int f = 1; f < 6 && six; ++f) {
+                    const Leaf &lf = leaves[final_order[(size_t)(k + f)]];
+                    six = lf.cube == h.cube && lf.face == f;
+                }
+                if (!six) continue;
+                // the faces' binary32 culling boxes, their union, and each face's slot: the axis on which it is thin, the side it is on
+                float lo[6][3], hi[6][3], glo[3], ghi[3];
+                for (int f = 0; f < 6; ++f) cull_box(fs.prim_bounds[(size_t)(k + f)], lo[f], hi[f]);
+                bool finite = true;
+                for (int a = 0; a < 3; ++a) {
+                    glo[a] = lo[0][a];
+                    ghi[a] = hi[0][a];
+                    for (int f = 0; f < 6; ++f) {
+                        glo[a] = std::fmin(glo[a], lo[f][a]);
+                        ghi[a] = std::fmax(ghi[a], hi[f][a]);
+                        finite = finite && std::isfinite(lo[f][a]) && std::isfinite(hi[f][a]);
+                    }
+                }
+                if (!finite) continue;
+                int face_of_slot[6] = {-1, -1, -1, -1, -1, -1};
+                bool ok = true;
+                for (int f = 0; f < 6 && ok; ++f) {
+                    int axis = -1;
+                    double thin = 0.02; // a face has to be thinner than 2 % of the box on its axis to be one of its sides
+                    for (int a = 0; a < 3; ++a) {
+                        const double ext = (double)ghi[a] - (double)glo[a];
+                        const double rel = ext > 0.0 ? ((double)hi[f][a] - (double)lo[f][a]) / ext : 1.0;
+                        if (rel < thin) {
+                            thin = rel;
+                            axis = a;
+                        }
+                    }
+                    if (axis < 0) {
+                        ok = false;
+                        break;
+                    }
+                    const double mid = 0.5 * ((double)lo[f][axis] + (double)hi[f][axis]), gmid = 0.5 * ((double)glo[axis] + (double)ghi[axis]);
+                    const int slot = 2 * axis + (mid < gmid ? 0 : 1);
+                    if (face_of_slot[slot] >= 0) ok = false;
+                    face_of_slot[slot] = f;
+                }
+                if (!ok) continue;
+                RtCubeGroup cg{};
+                for (int a = 0; a < 3; ++a) {
+                    cg.outer_lo[a] = glo[a];
+                    cg.outer_hi[a] = ghi[a];
+                    cg.inner_lo[a] = hi[face_of_slot[2 * a]][a];     // where the low face's slab ends
+                    cg.inner_hi[a] = lo[face_of_slot[2 * a + 1]][a]; // where the high face's slab begins
+                }
+                // every derived box contains the face's own culling box (outer planes: by the union; inner planes: by construction --
+                // asserted all the same, and the slabs must not be inverted)
+                for (int sl = 0; sl < 6 && ok; ++sl) {
+                    const int f = face_of_slot[sl], a = sl / 2;
+                    for (int b = 0; b < 3 && ok; ++b) {
+                        const float dlo = (b == a && (sl & 1)) ? cg.inner_hi[a] : cg.outer_lo[b];
+                        const float dhi = (b == a && !(sl & 1)) ? cg.inner_lo[a] : cg.outer_hi[b];
+                        ok = dlo <= lo[f][b] && dhi >= hi[f][b] && dlo <= dhi;
+                    }
+                }
+                if (!ok) continue;
+                cg.first_prim = (uint32_t)k;
+                for (int sl = 0; sl < 6; ++sl) cg.faces |= (uint32_t)face_of_slot[sl] << (3 * sl);
+                fs.cube_groups.push_back(cg);
+                group_len[(size_t)k] = 6;
+                for (int f = 1; f < 6; ++f) group_len[(size_t)(k + f)] = 0;
+                k += 5;
+            }
+        }
+    }
+    fs.group_len = group_len;
+    // BVH over the non-hoisted leaves (a cube group is one leaf with the union of its faces' boxes)
     if (fs.n_hoisted < fs.n_leaf_prims) {
-        const int32_t r = build_bvh(fs.prim_bounds, fs.n_hoisted, fs.n_leaf_prims, &fs.host_nodes, &fs.max_depth);
+        std::vector<Aabb> item_bounds;
+        std::vector<int> item_head;
+        for (int k = fs.n_hoisted; k < fs.n_leaf_prims; ++k) {
+            if (group_len[(size_t)k] == 0) continue;
+            Aabb b = fs.prim_bounds[(size_t)k];
+            for (int f = 1; f < group_len[(size_t)k]; ++f) b = merged(b, fs.prim_bounds[(size_t)(k + f)]);
+            item_bounds.push_back(b);
+            item_head.push_back(k);
+        }
+        int32_t r = build_bvh(item_bounds, 0, (int)item_bounds.size(), &fs.host_nodes, &fs.max_depth);
+        // leaf references of the items -> of their (head) prims
+        auto to_prim = [&](int32_t c) { return c >= 0 ? c : ~item_head[(size_t)(~c)]; };
+        r = to_prim(r);
+        for (HostNode &h : fs.host_nodes)
+            for (int c = 0; c < 2; ++c) h.child[c] = to_prim(h.child[c]);
         // up to 32767 prims and nodes: 16-bit references (one LDS word per stack entry); beyond: 32-bit ones
         fs.wide = (size_t)fs.n_leaf_prims > RT_REF_MAX || fs.host_nodes.size() > RT_REF_MAX;
         if (fs.wide) fs.feature_mask |= RT_FEAT_WIDE;
@@ -946,9 +1058,38 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
             }
             fs.nodes.push_back(n);
         }
+        // the same nodes with binary16 planes (RtNodeH), for an LDS copy where the binary32 form does not fit: every plane rounded
+        // outward once more, onto the binary16 grid.  Not built when a plane is not finite or too large for that grid.
+        if (!fs.wide) {
+            bool ok = true;
+            std::vector<RtNodeH> half;
+            for (const RtNode &n : fs.nodes) {
+                RtNodeH h{};
+                const float *lo[3] = {n.lo_x, n.lo_y, n.lo_z}, *hi[3] = {n.hi_x, n.hi_y, n.hi_z};
+                uint16_t *hlo[3] = {h.lo_x, h.lo_y, h.lo_z}, *hhi[3] = {h.hi_x, h.hi_y, h.hi_z};
+                for (int a = 0; a < 3 && ok; ++a)
+                    for (int c = 0; c < 2 && ok; ++c) {
+                        ok = std::isfinite(lo[a][c]) && std::isfinite(hi[a][c]) && std::fabs(lo[a][c]) <= 60000.0f && std::fabs(hi[a][c]) <= 60000.0f;
+                        hlo[a][c] = half_toward(lo[a][c], false);
+                        hhi[a][c] = half_toward(hi[a][c], true);
+                    }
+                h.child[0] = (uint16_t)n.child[0];
+                h.child[1] = (uint16_t)n.child[1];
+                half.push_back(h);
+            }
+            if (ok) fs.nodes_half = std::move(half);
+        }
     } else {
         fs.root = RT_CUR_DONE; // every prim is hoisted (only possible in the 16-bit form)
         fs.max_depth = 0;
+    }
+    // the cube groups' records behind the prims in prim_geo (two slots each), the head prim's meta word and aux pointing at them
+    for (const RtCubeGroup &cg : fs.cube_groups) {
+        const size_t at = fs.prim_geo.size();
+        fs.prim_geo.resize(at + 2);
+        std::memcpy(&fs.prim_geo[at], &cg, sizeof cg);
+        fs.prim_meta[cg.first_prim].kind |= RT_META_GROUP_BIT;
+        fs.prim_meta[cg.first_prim].aux = (uint32_t)at;
     }
     // Small general scenes (the Cornell box: 18 leaves) are walked as a LIST: every lane of a wave tests all the leaves'
     // culling boxes in lock step (rtl::trav_list_step) instead of descending a five-level tree with half the wave idle, then
@@ -985,7 +1126,7 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
         m.kind = (m.kind & ~0xFF00u) | (mk << 8);
     }
     // the kernels address every scene array with a 32-bit byte offset built from a 24-bit record index (rtl::rec_at)
-    const size_t most = std::max({fs.prim_meta.size(), fs.xforms.size(), fs.materials.size(), fs.textures.size(), fs.nodes.size()});
+    const size_t most = std::max({fs.prim_meta.size(), fs.prim_geo.size(), fs.xforms.size(), fs.materials.size(), fs.textures.size(), fs.nodes.size()});
     if (most > (size_t)RT_MAX_RECORDS || fs.image_blob.size() >= ((size_t)1 << 32)) {
         if (err) *err = "more than 2^24 records in one scene array (prims, transforms, materials, textures, nodes) or 4 GiB of texels";
         return RT_ERR_UNSUPPORTED;

@@ -6,7 +6,9 @@
 
 #include "rt_types.h"
 
+#include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -60,6 +62,9 @@ struct HostNode {
 struct FlatScene {
     std::vector<HostNode> host_nodes;
     std::vector<RtNode> nodes;
+    std::vector<RtNodeH> nodes_half;      // the same tree with binary16 planes (empty: not representable, or no tree)
+    std::vector<RtCubeGroup> cube_groups; // leaves that stand for the six faces of one cube (their records also sit behind the prims in prim_geo)
+    std::vector<int> group_len;           // per leaf prim: 6 at the head of a cube group, 0 at its other five faces, 1 otherwise
     // prims [0, n_hoisted) are scene-filling and tested directly; [n_hoisted, n_leaf_prims)
     // are BVH leaves; the rest are the boundary prims of general media
     std::vector<RtPrimMeta> prim_meta;
@@ -111,6 +116,46 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err);
 int32_t build_bvh(const std::vector<Aabb> &bounds, int first, int n, std::vector<HostNode> *nodes, int *max_depth);
 // binary32 culling box of a binary64 box: rounded outward, then padded
 void cull_box(const Aabb &b, float lo[3], float hi[3]);
+// binary32 -> binary16 bit pattern, rounded toward +inf (up) or -inf: the nearest grid value not inside the box.  |x| <= 60000.
+inline uint16_t half_toward(float x, bool up) {
+    auto to_float = [](uint16_t h) {
+        const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+        uint32_t bits;
+        if (e != 0u) {
+            bits = sign | ((e + 112u) << 23) | (m << 13);
+        } else {
+            const float sub = (float)m * 0x1p-24f;
+            std::memcpy(&bits, &sub, sizeof bits);
+            bits |= sign;
+        }
+        float f;
+        std::memcpy(&f, &bits, sizeof f);
+        return f;
+    };
+    // truncate the magnitude to the grid (toward zero), then step away from zero when that is the wrong side
+    uint32_t b;
+    std::memcpy(&b, &x, sizeof b);
+    const uint32_t sign = b >> 31;
+    const float ax = std::fabs(x);
+    uint16_t mag;
+    if (ax < 0x1p-14f) {
+        mag = (uint16_t)(ax * 0x1p24f); // subnormal grid: multiples of 2^-24 (truncation of an exact product)
+    } else {
+        uint32_t ab;
+        std::memcpy(&ab, &ax, sizeof ab);
+        mag = (uint16_t)((((ab >> 23) - 112u) << 10) | ((ab >> 13) & 0x3FFu));
+    }
+    uint16_t h = (uint16_t)((sign << 15) | mag);
+    const float back = to_float(h);
+    if (up ? back < x : back > x) { // one step further in the wanted direction
+        if ((up && !sign) || (!up && sign))
+            h = (uint16_t)(h + 1u); // away from zero
+        else
+            h = (uint16_t)(mag == 0u ? (up ? 0x0001u : 0x8001u) : h - 1u); // toward (and through) zero
+    }
+    return h;
+}
+
 
 // PerspectiveCamera::new (src/camera.rs:25-59)
 void camera_perspective(RtCameraD *out, const double eye[3], const double center[3], const double up[3], double fov,

@@ -61,7 +61,10 @@
 #define RT_BLOCK_GENERAL 256 /* kernel with media over general boundaries: 3 waves per SIMD as three groups per CU */
 #endif
 #ifndef RT_BLOCK_MEDIUM
-#define RT_BLOCK_MEDIUM 256 /* general prims + sphere media + textures (the book-two cover): 3 waves per SIMD as three groups per CU */
+#define RT_BLOCK_MEDIUM 1024 /* general prims + sphere media + textures (the book-two cover): ONE workgroup of sixteen waves per CU (round 5; four 256-thread
+                                groups until then).  One copy of the node array serves the whole CU -- with binary16 planes the cover's tree of 1406
+                                nodes over cube groups fits beside the stack -- and the class queues keep their 64 entries: the cover with its nodes
+                                still in global memory 98.6 -> 95.8 ms at 300 spp (profiles/r05_logs/cover_lds_probe0.log) */
 #endif
 // the general kernel without medium / texture code (Cornell box) needs 157 VGPRs = 3 waves per SIMD: three workgroups
 // of 4 waves (one per SIMD) per CU.  6-wave groups (384 threads) do NOT work: the second group no longer fits the
@@ -150,10 +153,13 @@
 namespace {
 
 // 16-bit references: one LDS word per entry = tnear truncated to its upper 16 bits | reference
-template <int BLOCK>
+// HALF: the node copy in LDS holds RtNodeH records (binary16 planes, 32 bytes: rtl::trav_node_step)
+template <int BLOCK, bool HALF = false>
 struct LdsStack {
     typedef RtRef16 Ref;
     static constexpr unsigned kEntryBytes = 4;
+    static constexpr bool kHalfNodes = HALF;
+    static constexpr bool kCubeGroups = true; // a leaf may be a cube group (rtl::trav_leaf_step; the host forms them for these walks only)
     uint32_t *base; // &stack[threadIdx.x]
     __device__ __forceinline__ void set(unsigned char *lds) { base = reinterpret_cast<uint32_t *>(lds) + threadIdx.x; }
     __device__ __forceinline__ void push(int32_t &sp, float tnear, uint32_t ref) {
@@ -207,16 +213,16 @@ struct LdsStackList {
         *ref = Ref::kLeaf | (e & ((1u << RT_LIST_PRIM_BITS) - 1u));
     }
 };
-template <int BLOCK, bool WIDE, bool LIST>
+template <int BLOCK, bool WIDE, bool LIST, bool HALF>
 struct StackOf {
-    typedef LdsStack<BLOCK> type;
+    typedef LdsStack<BLOCK, HALF> type;
 };
 template <int BLOCK>
-struct StackOf<BLOCK, true, false> {
+struct StackOf<BLOCK, true, false, false> {
     typedef LdsStackWide<BLOCK> type;
 };
 template <int BLOCK>
-struct StackOf<BLOCK, false, true> {
+struct StackOf<BLOCK, false, true, false> {
     typedef LdsStackList<BLOCK> type;
 };
 // workgroup size and waves per SIMD of each kernel family
@@ -291,13 +297,15 @@ __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__bui
 extern __shared__ __attribute__((aligned(16))) unsigned char rt_lds[];
 
 // LIST: the scene's leaves are a box list in LDS instead of a tree (small general scenes, rtl::trav_list_step)
-template <bool GENERAL, int MEDIUM, bool TEXTURED, bool LENS, bool COUNT, bool LDSNODES, bool SWAP, bool WIDE, bool LIST, bool RECLDS>
+// HALF: the LDS copy of the node array holds RtNodeH records (binary16 planes: half the bytes, the same slab test)
+template <bool GENERAL, int MEDIUM, bool TEXTURED, bool LENS, bool COUNT, bool LDSNODES, bool SWAP, bool WIDE, bool LIST, bool RECLDS, bool HALF = false>
 __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM)) void render_kernel(const RtLaunch L) {
     constexpr int kBlock = block_of(GENERAL, MEDIUM);
     // the lane program's GENERAL: 0 spheres only, 1 general prims with their records in global memory, 2 (RECLDS: box-LIST scenes
     // whose records fit) with the records in this workgroup's LDS (rt_lane.h rec_at<true>)
     constexpr int G = GENERAL ? (RECLDS ? 2 : 1) : 0;
-    typedef typename StackOf<kBlock, WIDE, LIST>::type Stack;
+    static_assert(!HALF || (LDSNODES && !WIDE && !LIST), "binary16 nodes exist as the LDS copy of a 16-bit tree only");
+    typedef typename StackOf<kBlock, WIDE, LIST, HALF>::type Stack;
     typedef typename Stack::Ref Ref;
     // entries per class queue: the most (<= RT_SWAP_CAP) that leaves the kernel family's full occupancy resident (host)
     // (a compile-time constant for the 512-thread families: the address arithmetic of a run-time capacity costs the
@@ -306,7 +314,8 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
     Stack st;
     constexpr uint32_t kStackEntry = Stack::kEntryBytes;
     const RtNode *nodes = L.nodes;
-    const uint32_t node_lds_bytes = LDSNODES ? (uint32_t)L.n_nodes * (uint32_t)sizeof(RtNode) : 0u;
+    constexpr uint32_t kNodeBytes = HALF ? (uint32_t)sizeof(RtNodeH) : (uint32_t)sizeof(RtNode);
+    const uint32_t node_lds_bytes = LDSNODES ? (uint32_t)L.n_nodes * kNodeBytes : 0u;
     // ONE layout function for host and device (rt_lds.h); a launch that provides fewer bytes than it needs is refused
     // instead of run: every wave returns at once and the host reports RT_ERR_DEVICE
     constexpr uint32_t kTableBytes = rt_lds_front_bytes(MEDIUM != 0 || TEXTURED);
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
     if (LDSNODES) {
         uint4 *dst = reinterpret_cast<uint4 *>(rt_lds + lay.node_off);
         const uint4 *src = reinterpret_cast<const uint4 *>(L.nodes);
-        const int n16 = L.n_nodes * (int)(sizeof(RtNode) / 16);
+        const int n16 = L.n_nodes * (int)(kNodeBytes / 16u);
         for (int i = (int)threadIdx.x; i < n16; i += kBlock) dst[i] = src[i];
         nodes = reinterpret_cast<const RtNode *>(dst);
     }
@@ -953,9 +962,9 @@ __global__ void probe_libm_kernel(int which, const double *a, const double *b, i
 // ---- dispatch over the template instantiations ----
 typedef void (*KernelFn)(const RtLaunch);
 
-template <bool GENERAL, int MEDIUM, bool TEXTURED, bool SWAP, bool WIDE = false, bool LIST = false, bool RECLDS = false>
+template <bool GENERAL, int MEDIUM, bool TEXTURED, bool SWAP, bool WIDE = false, bool LIST = false, bool RECLDS = false, bool HALF = false>
 KernelFn pick3(bool lens, bool count, bool ldsnodes) {
-#define RT_PICK(LN, C, LD) return render_kernel<GENERAL, MEDIUM, TEXTURED, LN, C, (LD && !WIDE) || LIST, SWAP, WIDE, LIST, RECLDS>
+#define RT_PICK(LN, C, LD) return render_kernel<GENERAL, MEDIUM, TEXTURED, LN, C, (LD && !WIDE) || LIST || HALF, SWAP, WIDE, LIST, RECLDS, HALF>
     if (lens) {
         if (count) {
             if (ldsnodes) RT_PICK(true, true, true); else RT_PICK(true, true, false);
@@ -973,7 +982,7 @@ KernelFn pick3(bool lens, bool count, bool ldsnodes) {
 }
 // lds_mode: bit 0 = node array copied to LDS, bit 1 = swap-at-shade queues, bit 2 = 32-bit references (general families),
 // bit 3 = box list instead of the tree (general families, 16-bit references, always in LDS), bit 4 = (list + swap only) the scene's
-// records in LDS
+// records in LDS, bit 5 = (with bits 0 and 1; the family with sphere media / textures only) the LDS copy holds RtNodeH records
 #if RT_TU_PART == 0 || RT_TU_PART == 3
 // media inside the boundary of media (feature bit 16): MEDIUM = 3, the only family compiled with the nested evaluation (a real
 // call per inner medium, records in scratch memory: 6 x slower than MEDIUM = 2 on the same scene, so it is kept out of it).
@@ -998,6 +1007,8 @@ KernelFn pick_media(unsigned features, bool lens, bool count, int lds_mode) {
         if (features & 8u) return swap ? pick3<true, 2, true, true, true>(lens, count, false) : pick3<true, 2, true, false, true>(lens, count, false);
         return swap ? pick3<true, 1, true, true, true>(lens, count, false) : pick3<true, 1, true, false, true>(lens, count, false);
     }
+    // the cover's family with its tree in binary16 (rt_api.cpp takes this form when the binary32 nodes do not fit the LDS and these do)
+    if (!(features & 8u) && swap && ldsnodes && (lds_mode & 32) != 0) return pick3<true, 1, true, true, false, false, false, true>(lens, count, true);
     // media over a general boundary (bit 8): the kernel with medium_general_hit; else the one with sphere media only
     if (features & 8u) return swap ? pick3<true, 2, true, true>(lens, count, ldsnodes) : pick3<true, 2, true, false>(lens, count, ldsnodes);
     return swap ? pick3<true, 1, true, true>(lens, count, ldsnodes) : pick3<true, 1, true, false>(lens, count, ldsnodes);

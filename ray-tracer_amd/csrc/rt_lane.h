@@ -947,6 +947,16 @@ RT_HD void trav_pop(Trav &tv, Stack &st) {
 // Returns true for a segment that runs (all but) in an axis plane -- some |d_i| below 2^-29 of the largest, zero included: the
 // one kind of ray that does not use the culling structure at all (trav_begin, ref_box_hit).  The test rides on the rare branch
 // the reciprocals needed anyway: three binary32 operations per segment.
+// does the Stack policy's node array hold RtNodeH records (binary16 planes, 32 bytes)?  (a policy without the member: no)
+template <class S, class = void>
+struct StackHalfNodes {
+    static constexpr bool value = false;
+};
+template <class S>
+struct StackHalfNodes<S, decltype((void)S::kHalfNodes)> {
+    static constexpr bool value = S::kHalfNodes;
+};
+template <bool HALFNODES = false>
 RT_HD bool trav_ray_constants(const RtLaunch &L, V3 o, V3 d, Trav &tv) {
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
     tv.idx = rcp32((float)d.x);
@@ -975,7 +985,8 @@ RT_HD bool trav_ray_constants(const RtLaunch &L, V3 o, V3 d, Trav &tv) {
     tv.fz = -(qz - ez);
     // sign bit of 1/d picks the entry plane of each axis (an infinite or NaN reciprocal only ever removes constraints)
     // (list mode, trav_list_step: byte offset inside a list box of the {entry, exit} plane pair of each axis)
-    const uint32_t flip = L.n_list ? 4u : 24u, ay = L.n_list ? 12u : 8u, az = L.n_list ? 24u : 16u;
+    // (RtNodeH: lo_x at byte 0, lo_y 4, lo_z 8, the hi_* planes 12 bytes on; the exit pair is at ox ^ 12, oy ^ 20, oz ^ 28)
+    const uint32_t flip = HALFNODES ? 12u : (L.n_list ? 4u : 24u), ay = HALFNODES ? 4u : (L.n_list ? 12u : 8u), az = HALFNODES ? 8u : (L.n_list ? 24u : 16u);
     tv.ox = (f32_bits(tv.idx) >> 31) * flip;
     tv.oy = (f32_bits(tv.idy) >> 31) * flip + ay;
     tv.oz = (f32_bits(tv.idz) >> 31) * flip + az;
@@ -1000,7 +1011,7 @@ RT_HD int32_t launch_n_prims(const RtLaunch &L) { return L.n_prims; }
 
 template <int GENERAL, int MEDIUM, class Stack>
 RT_HD void trav_begin(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack &st) {
-    const bool near_plane = trav_ray_constants(L, o, d, tv);
+    const bool near_plane = trav_ray_constants<StackHalfNodes<Stack>::value>(L, o, d, tv);
     tv.best_t = RTL_INF;
     tv.best_prim = 0xFFFFFFFFu;
     const double a = dot(d, d);
@@ -1060,8 +1071,56 @@ RT_HD F2 ld_pair(const RtNode *base, uint32_t byte_off) { // base: a node (LDS c
 // GLOBAL: the node array is in global memory: every load is `array base (SGPRs) + one 32-bit offset` (seven v_add_u32 instead
 // of seven 64-bit v_lshl_add_u64 and six VGPR pairs of offsets: -2 % on the book-two cover); the LDS copy keeps node pointer +
 // plane offset (one v_lshl_add_u32 for the node, one v_add_u32 per plane)
+// a (child0, child1) pair of binary16 planes of an RtNodeH, widened (exactly) to binary32: on the device the widening happens
+// inside the multiply-add that consumes it (v_fma_mix_f32 reads either half of the word as a binary16 operand)
+#if defined(__HIP_DEVICE_COMPILE__)
+struct H2 {
+    _Float16 a, b;
+};
+RT_HD H2 ld_pair_h(const unsigned char *node, uint32_t byte_off) { return *reinterpret_cast<const H2 *>(node + byte_off); }
+#else
+RT_HD float half_bits_to_float(uint32_t h) { // IEEE binary16 -> binary32, exact
+    const uint32_t sign = (h & 0x8000u) << 16, e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+    if (e == 0x1Fu) return bits_f32(sign | 0x7F800000u | (m << 13));
+    if (e != 0u) return bits_f32(sign | ((e + 112u) << 23) | (m << 13));
+    const float sub = (float)m * 0x1p-24f; // subnormal (or zero): m * 2^-24, exact
+    return sign ? -sub : sub;
+}
+typedef F2 H2;
+RT_HD H2 ld_pair_h(const unsigned char *node, uint32_t byte_off) {
+    const uint16_t *p = reinterpret_cast<const uint16_t *>(node + byte_off);
+    H2 r;
+    r.a = half_bits_to_float(p[0]);
+    r.b = half_bits_to_float(p[1]);
+    return r;
+}
+#endif
 template <bool GLOBAL = false, class Stack>
 RT_HD void trav_node_step(const RtNode *nodes, Trav &tv, Stack &st) {
+    if constexpr (StackHalfNodes<Stack>::value) {
+        // RtNodeH (the LDS copy only): the same slab test on the planes' binary16 images, which contain the binary32 boxes
+        const unsigned char *N = reinterpret_cast<const unsigned char *>(nodes) + tv.cur * (uint32_t)sizeof(RtNodeH);
+        const H2 px = ld_pair_h(N, tv.ox), py = ld_pair_h(N, tv.oy), pz = ld_pair_h(N, tv.oz);
+        const H2 qx = ld_pair_h(N, tv.ox ^ 12u), qy = ld_pair_h(N, tv.oy ^ 20u), qz = ld_pair_h(N, tv.oz ^ 28u);
+        const uint32_t cw = *reinterpret_cast<const uint32_t *>(N + 24u);
+        const uint32_t c0 = cw & 0xFFFFu, c1 = cw >> 16;
+        const float tmin0 = fmaxf(fmaxf(fmaf((float)px.a, tv.idx, tv.nx), fmaf((float)py.a, tv.idy, tv.ny)), fmaxf(fmaf((float)pz.a, tv.idz, tv.nz), 0.0f));
+        const float tmin1 = fmaxf(fmaxf(fmaf((float)px.b, tv.idx, tv.nx), fmaf((float)py.b, tv.idy, tv.ny)), fmaxf(fmaf((float)pz.b, tv.idz, tv.nz), 0.0f));
+        const float tmax0 = fminf(fminf(fmaf((float)qx.a, tv.idx, tv.fx), fmaf((float)qy.a, tv.idy, tv.fy)), fminf(fmaf((float)qz.a, tv.idz, tv.fz), tv.best32));
+        const float tmax1 = fminf(fminf(fmaf((float)qx.b, tv.idx, tv.fx), fmaf((float)qy.b, tv.idy, tv.fy)), fminf(fmaf((float)qz.b, tv.idz, tv.fz), tv.best32));
+        const bool h0 = tmin0 <= tmax0 * 1.000002f, h1 = tmin1 <= tmax1 * 1.000002f;
+        const bool one_first = tmin1 < tmin0;
+        const bool both = h0 && h1;
+        const uint32_t first = both ? (one_first ? c1 : c0) : (h0 ? c0 : c1);
+        const uint32_t second = one_first ? c0 : c1;
+        const float second_t = one_first ? tmin0 : tmin1;
+        if (both) st.push(tv.sp, second_t, second);
+        if (h0 || h1)
+            tv.cur = first;
+        else
+            trav_pop(tv, st);
+        return;
+    }
     const uint32_t nb = GLOBAL ? rec_off<RtNode>(tv.cur) : 0u;
     const RtNode *N = GLOBAL ? nodes : &nodes[tv.cur];
     const F2 px = ld_pair(N, nb + tv.ox), py = ld_pair(N, nb + tv.oy), pz = ld_pair(N, nb + tv.oz);                   // entry planes
@@ -1125,18 +1184,87 @@ RT_HD void trav_list_step(const float *boxes, uint32_t n, uint32_t first_prim, T
     tv.cur = near_ref; // kDone when no box is hit (nothing was pushed then)
 }
 
-// one leaf step (tv.cur is a leaf reference): binary64 primitive test, then pop
+// The kernel families whose tree leaves may be cube groups (RT_META_GROUP_BIT; rt_host.cpp forms groups for these families only):
+// general prims with the tree walk, without and with sphere media / textures.  (Box-LIST scenes and 32-bit references: never.)
+template <class S, class = void>
+struct StackCubeGroups { // a Stack policy says so itself (kCubeGroups): the 16-bit tree walks do, the list walk and the wide one do not
+    static constexpr bool value = false;
+};
+template <class S>
+struct StackCubeGroups<S, decltype((void)S::kCubeGroups)> {
+    static constexpr bool value = S::kCubeGroups;
+};
+template <int GENERAL, int MEDIUM, class Stack>
+struct CubeGroups {
+    static constexpr bool value = GENERAL == 1 && MEDIUM <= 1 && StackCubeGroups<Stack>::value;
+};
+
+// one leaf step (tv.cur is a leaf reference): binary64 primitive test, then pop.
+// A leaf that is the head of a CUBE GROUP stands for six rectangle prims: the culling boxes of the six faces are derived from the
+// group's twelve planes (RtCubeGroup) with the slab arithmetic of trav_node_step -- entry faces share the box's entry time, exit
+// faces its exit time -- and the faces whose box the ray crosses in [0, best] are tested nearest first, each lane its own next
+// candidate in the same pass of the loop; an ordinary leaf is the one-candidate case of the same loop (ONE inlined prim_hit).
 template <int GENERAL, int MEDIUM, class Stack>
 RT_HD void trav_leaf_step(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, Stack &st) {
-    const uint32_t pi = tv.cur & Stack::Ref::kMask;
+    const uint32_t head = tv.cur & Stack::Ref::kMask;
     const double a = dot(d, d);
-    Rec r;
-    if (prim_hit<GENERAL, MEDIUM, false>(L, pi, o, d, a, sc, &r, false)) {
-        // nearest t; exact ties go to the lower prim id, whatever the visiting order
-        if (r.t < tv.best_t || (r.t == tv.best_t && pi < tv.best_prim)) {
-            tv.best_t = r.t;
-            tv.best_prim = pi;
-            tv.best32 = up32(r.t);
+    uint32_t cand = 1u;             // bit s: the prim of slot s is still to be tested (an ordinary leaf: slot 0, the prim itself)
+    float tn_exit_x = 0.0f, tn_exit_y = 0.0f, tn_exit_z = 0.0f, tn_entry = 0.0f; // where the ray enters each candidate's box
+    uint32_t faces = 0u; // three bits per candidate slot (0-2: entry face of x y z, 3-5: exit face): the face's prim is head + that
+    if constexpr (CubeGroups<GENERAL, MEDIUM, Stack>::value) {
+        const RtPrimMeta &HM = rec_at(L.prim_meta, head);
+        if (HM.kind & RT_META_GROUP_BIT) {
+            const RtCubeGroup &C = reinterpret_cast<const RtCubeGroup &>(rec_at(L.prim_geo, HM.aux));
+            const bool sx = (f32_bits(tv.idx) >> 31) != 0u, sy = (f32_bits(tv.idy) >> 31) != 0u, sz = (f32_bits(tv.idz) >> 31) != 0u;
+            // per axis: te the ray reaches the entry face's slab, ti leaves it; txi reaches the exit face's slab, tx leaves it
+            const float te_x = fmaf(sx ? C.outer_hi[0] : C.outer_lo[0], tv.idx, tv.nx), ti_x = fmaf(sx ? C.inner_hi[0] : C.inner_lo[0], tv.idx, tv.fx);
+            const float txi_x = fmaf(sx ? C.inner_lo[0] : C.inner_hi[0], tv.idx, tv.nx), tx_x = fmaf(sx ? C.outer_lo[0] : C.outer_hi[0], tv.idx, tv.fx);
+            const float te_y = fmaf(sy ? C.outer_hi[1] : C.outer_lo[1], tv.idy, tv.ny), ti_y = fmaf(sy ? C.inner_hi[1] : C.inner_lo[1], tv.idy, tv.fy);
+            const float txi_y = fmaf(sy ? C.inner_lo[1] : C.inner_hi[1], tv.idy, tv.ny), tx_y = fmaf(sy ? C.outer_lo[1] : C.outer_hi[1], tv.idy, tv.fy);
+            const float te_z = fmaf(sz ? C.outer_hi[2] : C.outer_lo[2], tv.idz, tv.nz), ti_z = fmaf(sz ? C.inner_hi[2] : C.inner_lo[2], tv.idz, tv.fz);
+            const float txi_z = fmaf(sz ? C.inner_lo[2] : C.inner_hi[2], tv.idz, tv.nz), tx_z = fmaf(sz ? C.outer_lo[2] : C.outer_hi[2], tv.idz, tv.fz);
+            // (fmaxf / fminf ignore a NaN operand, 0 * inf: such an axis drops out, as in trav_node_step)
+            const float t_in = fmaxf(fmaxf(te_x, te_y), fmaxf(te_z, 0.0f));             // every entry face's box begins here
+            const float t_out = fminf(fminf(tx_x, tx_y), fminf(tx_z, tv.best32));        // every exit face's box ends here
+            const float k = 1.000002f;                                                   // the slack of trav_node_step's comparison
+            // entry face of axis a: [te_a, ti_a] on its own axis, the box's interval on the other two
+            const bool e_x = t_in <= fminf(fminf(ti_x, tx_y), fminf(tx_z, tv.best32)) * k;
+            const bool e_y = t_in <= fminf(fminf(tx_x, ti_y), fminf(tx_z, tv.best32)) * k;
+            const bool e_z = t_in <= fminf(fminf(tx_x, tx_y), fminf(ti_z, tv.best32)) * k;
+            // exit face of axis a: [txi_a, tx_a] on its own axis
+            tn_exit_x = fmaxf(fmaxf(txi_x, te_y), fmaxf(te_z, 0.0f));
+            tn_exit_y = fmaxf(fmaxf(te_x, txi_y), fmaxf(te_z, 0.0f));
+            tn_exit_z = fmaxf(fmaxf(te_x, te_y), fmaxf(txi_z, 0.0f));
+            const bool x_x = tn_exit_x <= t_out * k, x_y = tn_exit_y <= t_out * k, x_z = tn_exit_z <= t_out * k;
+            tn_entry = t_in;
+            cand = (e_x ? 1u : 0u) | (e_y ? 2u : 0u) | (e_z ? 4u : 0u) | (x_x ? 8u : 0u) | (x_y ? 16u : 0u) | (x_z ? 32u : 0u);
+            // the prim of each slot: entry side of an axis = its LOW side for a positive direction (slot 2a), its high side else
+            const uint32_t gf = C.faces; // by the box's slots 2 * axis + side
+            const uint32_t x_lo = gf & 7u, x_hi = (gf >> 3) & 7u, y_lo = (gf >> 6) & 7u, y_hi = (gf >> 9) & 7u, z_lo = (gf >> 12) & 7u, z_hi = (gf >> 15) & 7u;
+            faces = (sx ? x_hi : x_lo) | ((sy ? y_hi : y_lo) << 3) | ((sz ? z_hi : z_lo) << 6) | ((sx ? x_lo : x_hi) << 9) | ((sy ? y_lo : y_hi) << 12) |
+                    ((sz ? z_lo : z_hi) << 15);
+        }
+    }
+    while (cand != 0u) {
+        uint32_t pi = head;
+        if constexpr (CubeGroups<GENERAL, MEDIUM, Stack>::value) {
+            // the next candidate of THIS lane: entry faces first (they begin at t_in <= every exit face's entry)
+            const uint32_t slot = (uint32_t)__builtin_ctz(cand);
+            cand &= cand - 1u;
+            const float tn = slot < 3u ? tn_entry : (slot == 3u ? tn_exit_x : (slot == 4u ? tn_exit_y : tn_exit_z));
+            if (tn > tv.best32) continue; // behind the best hit so far: the rule of trav_pop
+            pi = head + ((faces >> (3u * slot)) & 7u);
+        } else {
+            cand = 0u;
+        }
+        Rec r;
+        if (prim_hit<GENERAL, MEDIUM, false>(L, pi, o, d, a, sc, &r, false)) {
+            // nearest t; exact ties go to the lower prim id, whatever the visiting order
+            if (r.t < tv.best_t || (r.t == tv.best_t && pi < tv.best_prim)) {
+                tv.best_t = r.t;
+                tv.best_prim = pi;
+                tv.best32 = up32(r.t);
+            }
         }
     }
     trav_pop(tv, st);

@@ -17,7 +17,7 @@ struct rt_scene {
     rt::FlatScene flat;
     bool committed = false;
     int device = -1;
-    void *d_nodes = nullptr, *d_prim_meta = nullptr, *d_prim_geo = nullptr, *d_prim_extra = nullptr, *d_xforms = nullptr,
+    void *d_nodes = nullptr, *d_nodes_half = nullptr, *d_prim_meta = nullptr, *d_prim_geo = nullptr, *d_prim_extra = nullptr, *d_xforms = nullptr,
          *d_materials = nullptr, *d_textures = nullptr, *d_blob = nullptr, *d_scene_blob = nullptr;
     size_t device_bytes = 0;
     size_t workspace_limit = 0; // rt_scene_set_workspace_limit; 0 = default (rt_api.cpp sample_workspace_cap)
@@ -60,7 +60,7 @@ struct rt_scene {
     void release_device() {
         if (device >= 0) {
             (void)hipSetDevice(device);
-            for (void **p : {&d_nodes, &d_prim_meta, &d_prim_geo, &d_prim_extra, &d_xforms, &d_materials, &d_textures, &d_blob, &d_scene_blob}) {
+            for (void **p : {&d_nodes, &d_nodes_half, &d_prim_meta, &d_prim_geo, &d_prim_extra, &d_xforms, &d_materials, &d_textures, &d_blob, &d_scene_blob}) {
                 if (*p) (void)hipFree(*p);
                 *p = nullptr;
             }

@@ -65,6 +65,11 @@ enum RtPrimKind : uint32_t {
 // o' = o + inv_t, d' = d, p = p' + t, n = n' -- what the 4x4 products give for such a matrix, rounding for rounding)
 #define RT_META_CHAIN_SHIFT 16
 #define RT_META_TMASK_SHIFT 20
+// bit 24: this prim is the HEAD of a cube group -- six consecutive rectangle prims, the faces of one Cube::new (src/geometry.rs:254-286)
+// whose culling boxes are (all but) the six sides of one axis-aligned box -- and the acceleration structure's leaf stands for all
+// six: RtPrimMeta::aux of the head is the index in prim_geo of the group's RtCubeGroup record (two RtPrimGeo slots behind every prim).
+// The faces stay ordinary RT_PRIM_RECT_C prims: hit records, tie rule and the careful scan know nothing of groups.
+#define RT_META_GROUP_BIT (1u << 24)
 
 enum RtMaterialKind : uint32_t {
     RT_MAT_LAMBERTIAN = 0,
@@ -86,6 +91,34 @@ struct alignas(16) RtNode {
     uint32_t pad[2];
 }; // 64 B
 static_assert(sizeof(RtNode) == 64 && __builtin_offsetof(RtNode, child) == 48, "rtl::trav_node_step reads the planes and children by byte offset");
+
+// The same node with binary16 planes, for a copy in LDS when the binary32 form does not fit (rt_api.cpp render_range): the planes are
+// the binary32 culling planes rounded OUTWARD once more to the binary16 grid (rt_host.cpp half_nodes), so every box contains the
+// binary32 box it stands for and the slab test is the same arithmetic on a slightly larger box: `fma((float)plane16, 1/d, n)` is
+// one v_fma_mix_f32 -- the conversion is free.  Only built when every plane is finite and below 60000 in magnitude.
+struct alignas(16) RtNodeH {
+    uint16_t lo_x[2], lo_y[2], lo_z[2]; // binary16 bit patterns, [child]
+    uint16_t hi_x[2], hi_y[2], hi_z[2];
+    uint16_t child[2];                  // 16-bit references (RT_REF_*)
+    uint32_t pad;
+}; // 32 B
+static_assert(sizeof(RtNodeH) == 32 && __builtin_offsetof(RtNodeH, hi_x) == 12 && __builtin_offsetof(RtNodeH, child) == 24,
+              "rtl::trav_node_step reads the planes and children by byte offset");
+
+// A cube group (RT_META_GROUP_BIT): the six faces' culling boxes are the six sides of ONE box, so they are derived from twelve planes
+// instead of being stored (and walked) as six leaves under five nodes.  Per axis: the box's outer planes and, just inside them, the
+// inner planes that close the slab of the face on that side: face (axis a, low side) has the box [outer_lo_a, inner_lo_a] on axis a
+// and [outer_lo_b, outer_hi_b] on the other two.  Every derived box CONTAINS the face's own binary32 culling box (rt_host.cpp checks
+// it plane by plane before it forms the group), so it culls by the same rule as a leaf box of the tree: never a result.
+// slot = 2 * axis + side (0 low, 1 high).
+struct alignas(16) RtCubeGroup {
+    float outer_lo[3], outer_hi[3];
+    float inner_lo[3], inner_hi[3];
+    uint32_t first_prim;
+    uint32_t faces; // three bits per slot: which of the six prims (first_prim + 0 .. 5) is the face of slot s = (faces >> 3 s) & 7
+    uint32_t pad[2];
+}; // 64 B = two RtPrimGeo slots
+static_assert(sizeof(RtCubeGroup) == 64, "a cube group takes two prim_geo slots");
 
 struct alignas(16) RtPrimMeta {
     uint32_t kind;     // see RT_META_*: prim kind, material kind (the shade block classifies a hit with one load), chain

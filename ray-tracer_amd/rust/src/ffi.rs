@@ -239,6 +239,7 @@ extern "C" {
     pub fn rt_scene_copy_nodes(s: *const rt_scene, out: *mut c_double, max_nodes: c_int) -> c_int;
     pub fn rt_scene_hash(s: *const rt_scene, out: *mut u64) -> c_int;
     pub fn rt_scene_prim_bounds(s: *const rt_scene, prim: c_int, out: *mut c_double) -> c_int;
+    pub fn rt_scene_prim_group(s: *const rt_scene, prim: c_int) -> c_int;
     pub fn rt_probe_device_math(
         device: c_int,
         a: *const c_double,

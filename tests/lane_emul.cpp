@@ -74,9 +74,12 @@ struct Probe { // lane_emul_world_hit
     uint32_t prim = 0;
 } g_probe;
 // the LDS stacks of rt_kernels.hip in host memory: the 16-bit form truncates tnear exactly as the device does
-template <class R>
+// HALF: the node array holds RtNodeH records (the device's LDS copy with binary16 planes)
+template <class R, bool HALF = false>
 struct ArrayStack {
     typedef R Ref;
+    static constexpr bool kHalfNodes = HALF;
+    static constexpr bool kCubeGroups = R::kLeaf == RT_REF_LEAF; // as the device's 16-bit tree walks (rt_kernels.hip LdsStack)
     float t[RT_STACK_DEPTH];
     uint32_t r[RT_STACK_DEPTH];
     int high_water = 0;
@@ -94,10 +97,10 @@ struct ArrayStack {
 
 // One lane's state machine run to completion: the wave-vote loop of render_kernel only
 // decides WHEN a lane's next step runs, never what it computes.
-template <bool G, int M, bool T, bool LENS, class R = RtRef16>
+template <bool G, int M, bool T, bool LENS, class R = RtRef16, bool HALF = false>
 void run(const RtLaunch &L, int x0, int y0, int x1, int y1, double *out, double *samples_out, int sx, int sy,
          unsigned long long *cnt, int *stack_high) {
-    ArrayStack<R> st;
+    ArrayStack<R, HALF> st;
     if (g_probe.on) { // lane_emul_world_hit: one given ray through begin_segment and the walk, nothing shaded
         rtl::PathState ps;
         rtl::Trav tv;
@@ -180,6 +183,40 @@ void run(const RtLaunch &L, int x0, int y0, int x1, int y1, double *out, double 
 }
 } // namespace
 
+// 1: scenes whose tree exists with binary16 planes (FlatScene::nodes_half) are walked through it, as the device does when it keeps
+// that form in LDS (rt_api.cpp render_range)
+static int g_half_nodes = 0;
+extern "C" void lane_emul_half_nodes(int on) { g_half_nodes = on; }
+
+// The binary16 tree (FlatScene::nodes_half) against the binary32 one: every plane's binary16 image lies OUTSIDE the binary32 plane
+// it stands for (lower planes <=, upper planes >=), by at most one binary16 step, and the children are the same.
+// Returns the number of violations, -1 when the scene has no binary16 tree; *n_out = nodes checked
+extern "C" int lane_emul_half_tree_check(rt_scene *s, int *n_out) {
+    const rt::FlatScene &f = s->flat;
+    *n_out = (int)f.nodes_half.size();
+    if (f.nodes_half.empty()) return -1;
+    if (f.nodes_half.size() != f.nodes.size()) return 1 << 30;
+    int bad = 0;
+    for (size_t i = 0; i < f.nodes.size(); ++i) {
+        const RtNode &n = f.nodes[i];
+        const RtNodeH &h = f.nodes_half[i];
+        const float *lo[3] = {n.lo_x, n.lo_y, n.lo_z}, *hi[3] = {n.hi_x, n.hi_y, n.hi_z};
+        const uint16_t *hlo[3] = {h.lo_x, h.lo_y, h.lo_z}, *hhi[3] = {h.hi_x, h.hi_y, h.hi_z};
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 2; ++c) {
+                const float l = rtl::half_bits_to_float(hlo[a][c]), u = rtl::half_bits_to_float(hhi[a][c]);
+                // one binary16 step at the plane's magnitude: 2^-10 relative (2^-24 absolute in the subnormal range)
+                const float step_l = std::fmax(std::fabs(lo[a][c]) * 0x1p-10f, 0x1p-24f), step_u = std::fmax(std::fabs(hi[a][c]) * 0x1p-10f, 0x1p-24f);
+                if (!(l <= lo[a][c]) || !(lo[a][c] - l <= step_l)) ++bad;
+                if (!(u >= hi[a][c]) || !(u - hi[a][c] <= step_u)) ++bad;
+            }
+        if (h.child[0] != n.child[0] || h.child[1] != n.child[1]) ++bad;
+    }
+    return bad;
+}
+// rt::half_toward on its own: out[0] = the binary16 value next to x on the given side, as a float
+extern "C" float lane_emul_half_toward(float x, int up) { return rtl::half_bits_to_float(rt::half_toward(x, up != 0)); }
+
 // counters: samples, segments, nodes_visited, prims_tested, rng_draws
 extern "C" int lane_emul_render(rt_scene *s, const rt_camera *cam, int W, int H, int spp, int max_depth, uint64_t seed, int x0,
                                 int y0, int x1, int y1, double *out, double *samples_out, int sx, int sy,
@@ -229,6 +266,23 @@ extern "C" int lane_emul_render(rt_scene *s, const rt_camera *cam, int W, int H,
             run<false, 0, false, true>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
         else
             run<false, 0, false, false>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
+    } else if (!s->flat.cube_groups.empty() || (g_half_nodes && !s->flat.nodes_half.empty() && !s->flat.n_list && !s->flat.wide &&
+                                                !(s->flat.feature_mask & (RT_FEAT_MEDIUM_GENERAL | RT_FEAT_DEEP_CHAIN | RT_FEAT_MEDIUM_NESTED)))) {
+        // a scene with cube groups is served by the lane program for sphere media only (MEDIUM = 1: rtl::CubeGroups; the host forms
+        // groups for those kernel families alone); with lane_emul_half_nodes(1) the walk reads the binary16 tree (RtNodeH)
+        const bool half = g_half_nodes && !s->flat.nodes_half.empty();
+        if (half) L.nodes = reinterpret_cast<const RtNode *>(s->flat.nodes_half.data());
+        if (half) {
+            if (lens)
+                run<true, 1, true, true, RtRef16, true>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
+            else
+                run<true, 1, true, false, RtRef16, true>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
+        } else {
+            if (lens)
+                run<true, 1, true, true>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
+            else
+                run<true, 1, true, false>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);
+        }
     } else if (!s->flat.wide) {
         if (lens)
             run<true, 3, true, true>(L, x0, y0, x1, y1, out, samples_out, sx, sy, cnt, &hw);

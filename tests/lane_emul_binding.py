@@ -37,6 +37,30 @@ def load(name):
         return res + (samples,) if sample_pixel else res
 
 
+    _LIB.lane_emul_half_nodes.restype = None
+    _LIB.lane_emul_half_nodes.argtypes = [C.c_int]
+    _LIB.lane_emul_half_tree_check.restype = C.c_int
+    _LIB.lane_emul_half_tree_check.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    _LIB.lane_emul_half_toward.restype = C.c_float
+    _LIB.lane_emul_half_toward.argtypes = [C.c_float, C.c_int]
+
+
+    def half_nodes(on):
+        """walk trees through their binary16 form (FlatScene::nodes_half, RtNodeH) where it exists, as the device does from LDS"""
+        _LIB.lane_emul_half_nodes(1 if on else 0)
+
+
+    def half_tree_check(scene):
+        """-> (violations, nodes): every binary16 plane outside its binary32 plane by at most a step; -1: the scene has no such tree"""
+        n = C.c_int()
+        bad = _LIB.lane_emul_half_tree_check(scene._h, C.byref(n))
+        return bad, n.value
+
+
+    def half_toward(x, up):
+        return float(_LIB.lane_emul_half_toward(float(x), 1 if up else 0))
+
+
     _LIB.lane_emul_ball_check.restype = C.c_int
     _LIB.lane_emul_ball_check.argtypes = [C.c_uint64, C.c_uint64, C.c_int, _DP, _DP, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
 
@@ -151,7 +175,8 @@ def load(name):
     ns = types.SimpleNamespace(render=render, ball_check=ball_check, medium_forms=medium_forms, lds_layout=lds_layout, div3=div3,
                                sphere_roots=sphere_roots, sphere_t_world=sphere_t_world, rng_forms=rng_forms,
                                device_math=bool(_LIB.lane_emul_device_math()), set_rcp_mode=_LIB.lane_emul_set_rcp_mode,
-                               rcp_calls=lambda: int(_LIB.lane_emul_rcp_calls()), trace_pixel=trace_pixel, trace_segments=trace_segments, world_hit=world_hit, scene_blob_check=scene_blob_check, set_log_perturbation=_LIB.lane_emul_set_log_perturbation, name=name)
+                               rcp_calls=lambda: int(_LIB.lane_emul_rcp_calls()), trace_pixel=trace_pixel, trace_segments=trace_segments, world_hit=world_hit, scene_blob_check=scene_blob_check, set_log_perturbation=_LIB.lane_emul_set_log_perturbation, half_nodes=half_nodes,
+                               half_tree_check=half_tree_check, half_toward=half_toward, name=name)
     return ns
 
 

@@ -695,6 +695,9 @@ def test_swap_at_shade_never_changes_a_result(rt, scenes, gpu_device, monkeypatc
     desc = {"book_one": lambda: scenes.book_one(1, W / H), "cornell": lambda: scenes.cornell(W / H),
             "cover": lambda: scenes.cover(1, W / H)}[scene]()
     sc, cam = scenes.build_product(desc, device=gpu_device)
+    # (the cover's tree is kept in LDS with binary16 planes by the kernels with the queues only: slightly larger boxes, a few more
+    # node steps -- for the comparison of the counters both builds walk the binary32 tree)
+    monkeypatch.setenv("RT_NO_HALF_NODES", "1")
     monkeypatch.setenv("RT_SWAP", "0")
     plain, c0 = sc.render(cam, W, H, spp, 50, seed=5, counters=True)
     monkeypatch.setenv("RT_SWAP", "1")
@@ -704,6 +707,12 @@ def test_swap_at_shade_never_changes_a_result(rt, scenes, gpu_device, monkeypatc
         assert c0[k] == c1[k], k
     assert c0["swap_scattered"] == 0 and c1["swap_scattered"] > 0
     assert c1["swap_parked"] == c1["swap_pulled"]  # nothing is left behind in a queue
+    if scene == "cover":
+        monkeypatch.delenv("RT_NO_HALF_NODES")
+        half, c2 = sc.render(cam, W, H, spp, 50, seed=5, counters=True)
+        assert sc.last_launch_config()["lds_nodes"] == 2  # RtNodeH in LDS
+        assert np.array_equal(half, plain) and c2["segments"] == c0["segments"]
+        assert c0["nodes_visited"] <= c2["nodes_visited"] <= 1.05 * c0["nodes_visited"] and c2["prims_tested"] >= c0["prims_tested"]
 
 
 def test_lean_general_kernel_on_a_large_scene(rt, scenes, oracle, gpu_device):

@@ -254,9 +254,13 @@ def _check_bvh(sc):
         assert depth <= 24
         if ref < 0:
             p = ~ref
-            seen.append(p)
-            b = sc.prim_bounds(p)
-            assert np.all(b[:3] >= box[:3]) and np.all(b[3:] <= box[3:])
+            n = sc.prim_group(p)  # 1, or 6: the head of a cube group, one leaf for six consecutive prims
+            assert n in (1, 6)
+            for q in range(p, p + n):
+                assert sc.prim_group(q) == (n if q == p else 0)
+                seen.append(q)
+                b = sc.prim_bounds(q)
+                assert np.all(b[:3] >= box[:3]) and np.all(b[3:] <= box[3:])
             return depth
         nd = nodes[ref]
         deepest = 0
@@ -307,6 +311,14 @@ def test_flatten_cornell_and_cover(rt, scenes):
     assert info["n_prims"] == 2400 + 1 + 4 + 1 + 1 + 1 + 1000 and info["n_child_prims"] == 0
     assert info["feature_mask"] & rt.RT_FEAT_MEDIUM and info["feature_mask"] & rt.RT_FEAT_TEXTURED
     assert 1 <= info["n_hoisted"] <= 4  # the r = 5000 fog at least
+    # round 5: the 400 floor boxes (Cube::new under a pure translation) are cube groups -- 400 leaves instead of 2400, a tree of
+    # 1406 nodes instead of 3406 (45 KB with binary16 planes: it fits one workgroup's LDS beside the stack)
+    heads = [p for p in range(info["n_prims"]) if sc.prim_group(p) == 6]
+    assert len(heads) == 400 and heads[:3] == [1, 7, 13]
+    assert info["n_nodes"] == (info["n_prims"] - info["n_hoisted"] - 5 * 400) - 1 == 1406
+    # the Cornell box's two cubes are rotated (and the scene is a box list anyway): no groups there
+    sc2, _ = scenes.build_product(scenes.cornell(), device=-1)
+    assert all(sc2.prim_group(p) == 1 for p in range(18))
 
 
 def test_flatten_edge_cases(rt, scenes):

@@ -50,6 +50,78 @@ def test_cover_exact(scenes, oracle, lane_emul):
     assert cnt["rng_draws"] <= ocnt["rng_draws"]
 
 
+def test_cube_groups_and_the_binary16_tree_exact(scenes, oracle, lane_emul, lane_devmath, monkeypatch):
+    """Round 5: the cover's 400 floor boxes are CUBE GROUPS -- one leaf for the six faces of a cube, whose boxes the
+    leaf step derives from twelve planes (rtl::trav_leaf_step) -- and its tree of 1406 nodes also exists with binary16 planes
+    (RtNodeH), the form the device keeps in LDS.  Culling never reaches a result: with groups or without (RT_NO_CUBE_GROUPS=1),
+    through the binary32 tree or the binary16 one, in both arithmetic forms, the image is the oracle's, bit for bit."""
+    desc = scenes.cover(1, 1.0)
+    W = H = 48
+    sc, cam = scenes.build_product(desc, device=-1)
+    assert sum(1 for p in range(sc.info()["n_prims"]) if sc.prim_group(p) == 6) == 400
+    ref = oracle.build_oracle(desc).render(W, H, 4, 100, seed=3, iterative=True, nthreads=8)
+    bad, n = lane_emul.half_tree_check(sc)
+    assert bad == 0 and n == sc.info()["n_nodes"] == 1406
+    imgs = {}
+    for emul in (lane_emul, lane_devmath):
+        for half in (False, True):
+            emul.half_nodes(half)
+            try:
+                img, cnt, _ = emul.render(sc, cam, W, H, 4, 100, seed=3)
+            finally:
+                emul.half_nodes(False)
+            assert np.array_equal(img, ref), (emul.name, half)
+            imgs[(emul.name, half)] = cnt
+    # the binary16 boxes are (slightly) larger: never fewer node steps or primitive tests than through the binary32 tree
+    a, b = imgs[(lane_emul.name, False)], imgs[(lane_emul.name, True)]
+    assert b["nodes_visited"] >= a["nodes_visited"] and b["prims_tested"] >= a["prims_tested"]
+    assert b["nodes_visited"] <= 1.1 * a["nodes_visited"]  # ... and not many more: a step of 2^-10 of the coordinate
+    # without groups: 2400 face leaves, the tree of round 4 -- the same image, and the groups test no more primitives than that tree does
+    monkeypatch.setenv("RT_NO_CUBE_GROUPS", "1")
+    sc0, cam0 = scenes.build_product(desc, device=-1)
+    assert sc0.info()["n_nodes"] == 3406 and all(sc0.prim_group(p) == 1 for p in range(0, 3408, 97))
+    img0, cnt0, _ = lane_emul.render(sc0, cam0, W, H, 4, 100, seed=3)
+    assert np.array_equal(img0, ref)
+    assert a["prims_tested"] <= 1.15 * cnt0["prims_tested"], (a, cnt0)
+    monkeypatch.delenv("RT_NO_CUBE_GROUPS")
+    # rotated cubes are not grouped (their faces' boxes are not the sides of one box); cubes far from the origin and tiny ones are
+    d = scenes.SceneDesc()
+    m = d.lambertian_rgb((0.7, 0.6, 0.5))
+    for i, (size, at) in enumerate([(2.0, (0.0, 1.0, 0.0)), (1e-3, (3.0, 5e-4, 0.0)), (3.0, (4000.0, 1.5, 30.0))]):
+        d.sprite(d.geom("cube", size, size, size), m, scenes.mat4_translation(at))
+    d.sprite(d.geom("cube", 2.0, 2.0, 2.0), m, scenes.mat4_multiplied(scenes.mat4_translation((-3.0, 1.0, 0.0)), scenes.mat4_rotation(0.3, (0.0, 1.0, 0.0))))
+    for i in range(24):  # (enough other leaves to keep the scene off the box list)
+        d.sprite(d.geom("sphere", 0.3), m, scenes.mat4_translation((i - 12.0, 0.3, 4.0)))
+    d.sprite(d.geom("sphere", 2000.0), d.mat("diffuse_light", d.tex_solid((0.6, 0.7, 1.0))), None)
+    d.camera = ((0.0, 3.0, -12.0), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0), 0.7, 1.0, 10.0, 0.0)
+    sc, cam = scenes.build_product(d, device=-1)
+    groups = [p for p in range(sc.info()["n_prims"]) if sc.prim_group(p) == 6]
+    assert len(groups) == 3, groups
+    for half in (False, True):
+        lane_emul.half_nodes(half)
+        try:
+            img, _, _ = lane_emul.render(sc, cam, 40, 40, 4, 50, seed=2)
+        finally:
+            lane_emul.half_nodes(False)
+        assert np.array_equal(img, oracle.build_oracle(d).render(40, 40, 4, 50, seed=2, iterative=True, nthreads=8))
+
+
+def test_rounding_to_the_binary16_grid_is_outward():
+    """rt::half_toward: the nearest binary16 value on the asked side, for values across the grid's whole range (subnormals included)"""
+    import lane_emul_binding as le
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.uniform(-60000, 60000, 2000), rng.uniform(-1, 1, 2000) * 10.0 ** rng.uniform(-9, 0, 2000),
+                         [0.0, -0.0, 1.0, -1.0, 2.0 ** -14, 2.0 ** -24, 2.0 ** -25, 65504.0 * 0.9, 1e-30, -1e-30, 1024.0, 1023.999]]).astype(np.float32)
+    for x in xs:
+        lo, hi = le.half_toward(x, False), le.half_toward(x, True)
+        assert lo <= float(x) <= hi
+        assert np.float16(lo) == np.float32(lo) and np.float16(hi) == np.float32(hi)  # both are binary16 values
+        if float(np.float16(x)) == float(x):
+            assert lo == hi == float(x)   # on the grid: itself
+        else:
+            assert hi == float(np.nextafter(np.float16(lo), np.float16(np.inf)))  # neighbours on the grid
+
+
 def test_textured_and_rotated_primitives_exact(scenes, oracle, lane_emul):
     d = scenes.SceneDesc()
     black, white = d.tex_solid((0.05, 0.05, 0.05)), d.tex_solid((0.9, 0.9, 0.9))
