@@ -484,15 +484,17 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
         if (RT_LIST_LDS_ARRAYS & 8) L.prim_extra = (const RtPrimExtra *)(uintptr_t)(table + off[3]);
         if (RT_LIST_LDS_ARRAYS & 16) L.materials = (const RtMaterial *)(uintptr_t)(table + off[4]);
     }
-    int ldsnodes = list || (!wide && node_bytes > 0 && !(no_lds && *no_lds == '1') &&
+    const char *no_half = std::getenv("RT_NO_HALF_NODES");
+    const char *want_half = std::getenv("RT_HALF_NODES"); // 1: the binary16 form wherever it exists, also when the binary32 nodes would fit (sweeps, A/B)
+    const unsigned half_bytes = (unsigned)(s->flat.nodes_half.size() * sizeof(RtNodeH));
+    const bool half_possible = !list && !wide && swap && half_bytes > 0 && (feat & ~1u) != 0u && !(feat & (8u | 16u)) && !(no_lds && *no_lds == '1') &&
+                               !(no_half && *no_half == '1') && s->d_nodes_half &&
+                               rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, half_bytes, min_cap, front).total <= lds_share;
+    int ldsnodes = list || (!wide && node_bytes > 0 && !(no_lds && *no_lds == '1') && !(half_possible && want_half && *want_half == '1') &&
                             rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, node_bytes, min_cap, front).total <= lds_share);
     // the binary32 nodes do not fit: the same tree with binary16 planes (RtNodeH, half the bytes) may -- the family with sphere media /
     // textures has kernels for it (the book-two cover: 1406 nodes over cube groups, 45 KB beside a 56 KB stack).  RT_NO_HALF_NODES=1: never.
-    const char *no_half = std::getenv("RT_NO_HALF_NODES");
-    const unsigned half_bytes = (unsigned)(s->flat.nodes_half.size() * sizeof(RtNodeH));
-    const int half = !ldsnodes && !list && !wide && swap && half_bytes > 0 && (feat & ~1u) != 0u && !(feat & (8u | 16u)) && !(no_lds && *no_lds == '1') &&
-                     !(no_half && *no_half == '1') && s->d_nodes_half &&
-                     rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, half_bytes, min_cap, front).total <= lds_share;
+    const int half = !ldsnodes && half_possible;
     if (half) {
         ldsnodes = 1;
         L.nodes = (const RtNode *)s->d_nodes_half; // RtNodeH records: the kernel's HALF instantiation reads them as such

@@ -1,0 +1,23 @@
+#!/bin/bash
+# GPU box, round 5: tools/random_parity.py over fresh seeds with the round's kernels (cube groups, the binary16 tree in LDS).
+#   tools/r05_sweeps.sh <part>     part 1: cover + cubes; part 2: general; part 3: book-one, cameras, scaled, wide, x4
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+run() { # timeout n first depth generator [env...]
+  local t=$1 n=$2 first=$3 depth=$4 gen=$5; shift 5
+  env "$@" timeout -k 10 $t python3 tools/random_parity.py $n $first $depth $gen > gpurun_out/r05_sweep_${gen}_${first}.log 2>&1
+  tail -1 gpurun_out/r05_sweep_${gen}_${first}.log | cut -c1-420
+}
+case "$1" in
+1) run 400 2500 9100001 100 cover X=1
+   run 400 6000 9200001 40 cubes X=1
+   run 400 6000 9300001 40 cubes RT_HALF_NODES=1 ;;
+2) run 1100 30000 9400001 40 general X=1 ;;
+3) run 300 5000 9500001 100 book_one X=1
+   run 300 3000 9600001 100 camera X=1
+   run 300 3000 9700001 100 scaled X=1
+   run 200 50 9800001 100 wide X=1 ;;
+4) run 1100 10000 9900001 100 general X=1 ;;
+5) RANDOM_PARITY_SCALE=4 run 900 800 10000001 100 general X=1
+   RANDOM_PARITY_SCALE=4 run 200 200 10100001 100 cubes RT_HALF_NODES=1 ;;
+esac

@@ -18,7 +18,7 @@ from __graft_entry__ import load_package  # noqa: E402
 rt = load_package()
 scenes = importlib.import_module("ray_tracer_amd.scenes")
 import oracle_binding as oracle  # noqa: E402
-from test_random_scenes import camera_scene, random_scene, random_scene_r3, scaled_scene, wide_scene  # noqa: E402
+from test_random_scenes import camera_scene, cubes_scene, random_scene, random_scene_r3, scaled_scene, wide_scene  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 FIRST = int(sys.argv[2]) if len(sys.argv) > 2 else 100  # first scene seed
@@ -32,6 +32,12 @@ def make_scene(seed, aspect):
         return scenes.book_one(seed, aspect)
     if GEN == "cover":
         return scenes.cover(seed, aspect)
+    if GEN == "cubes":  # axis-aligned cubes: cube groups, the binary16 tree (RT_HALF_NODES=1 walks it whenever it exists)
+        # (scene seeds with seed % 4 < 2 only: the others snap the cubes to a grid, faces coincide, and at an exact tie the reference's
+        # answer depends on its random tree -- tests/test_random_scenes.py holds those to "every structure, one image" instead)
+        d = cubes_scene(scenes, (seed // 2) * 4 + seed % 2)
+        d.camera = d.camera[:4] + (aspect,) + d.camera[5:]
+        return d
     if GEN == "wide":
         return wide_scene(scenes, seed)
     if GEN == "scaled":
