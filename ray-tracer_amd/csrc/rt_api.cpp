@@ -500,7 +500,9 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
         L.nodes = (const RtNode *)s->d_nodes_half; // RtNodeH records: the kernel's HALF instantiation reads them as such
     }
     const unsigned in_lds = ldsnodes ? (half ? half_bytes : node_bytes) : 0u;
-    const unsigned swap_cap = swap ? rt_swap_cap_that_fits((unsigned)L.stack_entries, block, entry_bytes, in_lds, groups_per_cu, front) : 0u;
+    unsigned swap_cap = swap ? rt_swap_cap_that_fits((unsigned)L.stack_entries, block, entry_bytes, in_lds, groups_per_cu, front) : 0u;
+    if (const char *lim = std::getenv("RT_SWAP_CAP_LIMIT")) // A/B runs: fewer entries per class queue than would fit (not for the 512-thread family: compiled in)
+        if (block < 512u && std::atoi(lim) >= 16) swap_cap = std::min(swap_cap, (unsigned)std::atoi(lim)) & ~1u;
     L.swap_cap = (int)swap_cap;
     const RtLdsLayout lay = rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, in_lds, swap ? rt_swap_cap_effective(block, swap_cap) : 0u, front);
     if (!rt_lds_layout_aligned(lay)) return fail(RT_ERR_DEVICE, "internal: misaligned LDS layout");

@@ -97,7 +97,12 @@
 #define RT_VOTE_SHADE_LEAN 56
 #endif
 #ifndef RT_NODE_KEEP_G
-#define RT_NODE_KEEP_G 12 /* (8 until round 4; 16 / 12: 295.4, 16 / 16: 298.7, 24 / 16: 301.4, 32 / 16: 306.1, 8 / 24: 310.6) */
+#define RT_NODE_KEEP_G 12 /* node array in global memory (8 until round 4; 16 / 12: 295.4, 16 / 16: 298.7, 24 / 16: 301.4, 32 / 16: 306.1, 8 / 24: 310.6) */
+#endif
+// ... and when the node array lives in LDS a node step is cheap enough to leave the inner loop earlier (round 5, the cover with its
+// binary16 tree in LDS, 300 spp: 12: 81.4 ms, 8: 80.7, 6: 80.2, 4: 80.1, 20: 83.5; profiles/r05_logs/ab_cover_votes*.log)
+#ifndef RT_NODE_KEEP_G_LDS
+#define RT_NODE_KEEP_G_LDS 6
 #endif
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 4 /* spheres-only kernel: 105 VGPRs fit 4 waves per SIMD */
@@ -334,9 +339,10 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
     // words were copied out and back on every trip round the vote loop (25 v_mov per node-block visit)
     uint32_t *job_mem = reinterpret_cast<uint32_t *>(rt_lds + lay.job_off) + (threadIdx.x >> 6) * (RT_JOB_BYTES_PER_WAVE / 4u);
     if ((threadIdx.x & 63u) < 8u) job_mem[threadIdx.x & 63u] = (threadIdx.x & 63u) == 6u ? 1u : 0u; // job_nspp = 1, the rest 0
-    unsigned char *swap_mem = rt_lds + lay.swap_off;
+    // (a 1024-thread workgroup: one set of queues per eight waves, rt_lds.h rt_swap_sets; this wave's set)
+    unsigned char *swap_mem = rt_lds + lay.swap_off + (rt_swap_sets((uint32_t)kBlock) > 1u ? (threadIdx.x >> 9) * lay.swap_set_bytes : 0u);
     uint32_t *swap_hdr = reinterpret_cast<uint32_t *>(swap_mem);
-    if (SWAP && threadIdx.x < RT_SWAP_HDR_BYTES / 4u) swap_hdr[threadIdx.x] = 0u;
+    if (SWAP && (threadIdx.x & 511u) < RT_SWAP_HDR_BYTES / 4u) swap_hdr[threadIdx.x & 511u] = 0u;
     if (MEDIUM != 0 || TEXTURED) // the log table (rt_libm.h) at the front of the workgroup's LDS: rtl::log_cold reads it there
         for (uint32_t i = threadIdx.x; i < RT_LDS_LOG_TABLE_BYTES / 8u; i += (uint32_t)kBlock) reinterpret_cast<double *>(rt_lds)[i] = rtm_log_tab[i];
     if (G == 2) { // the scene's records (transforms, prims, materials), packed by the host in the layout the offsets in L assume
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(block_of(GENERAL, MEDIUM), waves_of(GENERAL, MEDIUM
         const int nS = __popcll(mS), nL = __popcll(mL), nN = __popcll(mN);
 
         constexpr int kVoteShade = GENERAL ? (MEDIUM == 0 ? RT_VOTE_SHADE_LEAN : RT_VOTE_SHADE_G) : RT_VOTE_SHADE, kVoteLeaf = GENERAL ? RT_VOTE_LEAF_G : RT_VOTE_LEAF,
-                      kNodeKeep = GENERAL ? RT_NODE_KEEP_G : RT_NODE_KEEP;
+                      kNodeKeep = GENERAL ? (LDSNODES ? RT_NODE_KEEP_G_LDS : RT_NODE_KEEP_G) : RT_NODE_KEEP;
         if (nS >= kVoteShade || (nN == 0 && nL == 0)) {
             // ---------------- shade block ----------------
             if (COUNT && counting_lane) {

@@ -9,6 +9,7 @@
 // launched with are fewer than the layout needs.
 //
 //   [ traversal stack: stack_entries x block x entry_bytes ][ node copy or box list (optional) ][ job state: 32 B per wave ]
+//   per set of queues (one per eight waves of a 1024-thread workgroup, else one):
 //   [ swap header 32 B ][ class 0 | class 1 | class 2 : RT_SWAP_F64 arrays of cap doubles, then RT_SWAP_F32 arrays of cap words ]
 #ifndef RT_LDS_H
 #define RT_LDS_H
@@ -41,10 +42,17 @@
 struct RtLdsLayout {
     uint32_t stack_off, node_off, job_off, swap_off; // byte offsets of the regions
     uint32_t swap_class_bytes;                       // one class queue
+    uint32_t swap_set_bytes;                         // one set of queues (header + classes); a workgroup has rt_swap_sets() of them
     uint32_t total;                                  // bytes the launch has to provide
 };
 
-// the capacity the kernel really uses: compiled in for the 512-thread family (run-time address arithmetic costs it 2 %),
+// One 1024-thread workgroup per CU (the family with sphere media / textures since round 5) would serve sixteen waves with ONE set of
+// class queues, i.e. three locks: measured on the cover, 1.86 M lock attempts given up per launch against 0.4 M with four 256-thread
+// groups, and 56 % of all scatters off class.  A workgroup therefore keeps one SET of queues per eight waves (the share a 512-thread
+// group's waves have): wave w parks into and pulls from set w / 8 only, each set with its own header and locks.
+RT_LDS_HD constexpr uint32_t rt_swap_sets(uint32_t block_threads) { return block_threads >= 1024u ? block_threads / 512u : 1u; }
+// the capacity the kernel really uses: compiled in for the families of 512 threads and more (run-time address arithmetic costs the
+// book-one kernel 2 %, the cover's 1.5 %: profiles/r05_logs/ab_cover_caps.log),
 // the launch's value (EVEN: a class is 124 x cap bytes and its binary64 arrays have to stay 8-byte aligned) for the others
 RT_LDS_HD constexpr uint32_t rt_swap_cap_effective(uint32_t block_threads, uint32_t launch_cap) {
     return block_threads >= 512u ? (uint32_t)RT_SWAP_CAP : (launch_cap & ~1u);
@@ -70,12 +78,13 @@ RT_LDS_HD constexpr RtLdsLayout rt_lds_layout(uint32_t stack_entries, uint32_t b
     l.job_off = l.node_off + ((node_bytes + 15u) & ~15u);
     l.swap_off = l.job_off + (block_threads / 64u) * RT_JOB_BYTES_PER_WAVE;
     l.swap_class_bytes = RT_SWAP_ENTRY_BYTES * swap_cap;
-    l.total = l.swap_off + (swap_cap ? RT_SWAP_HDR_BYTES + (uint32_t)RT_SWAP_CLASSES * l.swap_class_bytes : 0u);
+    l.swap_set_bytes = swap_cap ? RT_SWAP_HDR_BYTES + (uint32_t)RT_SWAP_CLASSES * l.swap_class_bytes : 0u; // header + three class queues
+    l.total = l.swap_off + rt_swap_sets(block_threads) * l.swap_set_bytes;
     return l;
 }
 // every region starts where its widest access needs it to
 RT_LDS_HD constexpr bool rt_lds_layout_aligned(const RtLdsLayout &l) {
-    return l.node_off % 16u == 0u && l.job_off % 16u == 0u && l.swap_off % 8u == 0u && l.swap_class_bytes % 8u == 0u;
+    return l.node_off % 16u == 0u && l.job_off % 16u == 0u && l.swap_off % 8u == 0u && l.swap_class_bytes % 8u == 0u && l.swap_set_bytes % 8u == 0u;
 }
 
 // The largest EVEN capacity (<= RT_SWAP_CAP) with which `groups_per_cu` workgroups of this shape still share one CU's LDS;
@@ -95,6 +104,8 @@ static_assert(rt_lds_layout_aligned(rt_lds_layout(24, 512, 4, 31 * 1024, RT_SWAP
 static_assert(rt_lds_layout_aligned(rt_lds_layout(17, 256, 4, 648, 38, RT_LDS_LOG_TABLE_BYTES)), "list shape, even capacity");
 static_assert(rt_lds_layout_aligned(rt_lds_layout(13, 256, 8, 0, 16, 0)), "wide references");
 static_assert(rt_lds_layout(10, 256, 4, 0, 0, 0).total == 10 * 256 * 4 + 4 * RT_JOB_BYTES_PER_WAVE, "no queues: stack + job state");
+static_assert(rt_lds_layout_aligned(rt_lds_layout(14, 1024, 4, 1406 * 32, RT_SWAP_CAP, RT_LDS_LOG_TABLE_BYTES)) &&
+              rt_lds_layout(14, 1024, 4, 1406 * 32, RT_SWAP_CAP, RT_LDS_LOG_TABLE_BYTES).total <= RT_LDS_PER_CU, "the book-two cover: two sets of queues beside its binary16 tree");
 
 // device error word (RtLaunch::status): set by the kernel, turned into RT_ERR_DEVICE by the host
 #define RT_DEV_OK 0u

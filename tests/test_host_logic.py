@@ -456,7 +456,8 @@ def test_lds_layout_is_aligned_and_fits_for_every_launch_shape(lane_emul):
     8 B, every class queue 8 B), the capacity is even, and `groups_per_cu` workgroups fit one CU's 160 KiB whenever the
     capacity is above the 16-entry floor."""
     nq = 3  # the three class queues: the layout has no other (rt_lds.h)
-    for block, groups, front in ((512, 2, 0), (256, 4, 0), (256, 3, 0), (256, 4, 2048), (256, 3, 2048)):  # front: the log table of the media families
+    # (1024, 1, 2048): the family with sphere media / textures since round 5 -- one workgroup per CU, one SET of queues per eight waves
+    for block, groups, front in ((512, 2, 0), (256, 4, 0), (256, 3, 0), (256, 4, 2048), (256, 3, 2048), (1024, 1, 2048)):  # front: the log table of the media families
         for entry_bytes in (2, 4, 8):
             for stack_entries in range(1, 25):
                 for node_bytes in (0, 64, 576, 648, 1024, 9 * 64, 250 * 64, 484 * 64, 1000 * 64):
@@ -467,9 +468,14 @@ def test_lds_layout_is_aligned_and_fits_for_every_launch_shape(lane_emul):
                     assert l["job_off"] >= l["node_off"] + node_bytes and l["swap_off"] == l["job_off"] + (block // 64) * 32
                     for cls in range(nq):  # every queue starts 8-byte aligned (its first 14 arrays are binary64)
                         assert (l["swap_off"] + 32 + cls * l["swap_class_bytes"]) % 8 == 0
-                    assert l["total"] == l["swap_off"] + 32 + nq * l["swap_class_bytes"]
+                    sets = block // 512 if block >= 1024 else 1
+                    assert l["total"] == l["swap_off"] + sets * (32 + nq * l["swap_class_bytes"])
+                    assert (32 + nq * l["swap_class_bytes"]) % 8 == 0  # the second set's binary64 arrays stay aligned
                     if l["cap"] > 16 and block < 512:
                         assert l["total"] <= (160 * 1024 // groups) // 512 * 512, l
+    # the book-two cover: a stack of 14 entries, 1406 nodes of 32 bytes, the log table, two sets of queues of 64: one CU's LDS holds it
+    l = lane_emul.lds_layout(14, 1024, 4, 1406 * 32, 1, 2048)
+    assert l["cap_effective"] == 64 and l["total"] == 2048 + 14 * 4096 + 1406 * 32 + 16 * 32 + 2 * (32 + 3 * 124 * 64) <= 160 * 1024
     # the case the advisor named: ~250 leaves with the node array in LDS used to get 39 entries; now an even 38
     l = lane_emul.lds_layout(12, 256, 4, 250 * 64, 4)
     assert l["cap"] % 2 == 0
