@@ -240,13 +240,13 @@ def rank_environment():
 
 
 def predicted_strong_scaling(n, ascending=False):
-    """profiles/r04_shard_scaling*.log (tools/shard_scaling.py): speed-up over N = 1 predicted from per-shard times measured on ONE
+    """profiles/r05_shard_scaling*.log (tools/shard_scaling.py): speed-up over N = 1 predicted from per-shard times measured on ONE
     MI355X (1/N shard of the image, render + sums, before the gather), in the learnt tile order or in ascending order: a prediction
     printed beside the measurement, never instead of it"""
-    return ({1: 1.0, 2: 1.96, 4: 3.80, 8: 7.09} if ascending else {1: 1.0, 2: 1.97, 4: 3.86, 8: 7.23}).get(n)
+    return ({1: 1.0, 2: 1.97, 4: 3.81, 8: 7.14} if ascending else {1: 1.0, 2: 1.97, 4: 3.85, 8: 7.25}).get(n)
 
 
-PREDICTION_KERNELS = "0b02c91c79c3db22"  # the kernel hash (rt_version) profiles/r04_shard_scaling*.log were measured with
+PREDICTION_KERNELS = "cbeb10b532277254"  # the kernel hash (rt_version) profiles/r05_shard_scaling*.log were measured with
 
 
 def main():
