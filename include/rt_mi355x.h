@@ -254,7 +254,8 @@ typedef struct rt_launch_config {
     int blocks_per_cu, n_cu;
     int passes, n_jobs, job_spp;
     unsigned kernel_features;
-    int lds_nodes, swap;
+    int lds_nodes, swap;          /* lds_nodes: 0 the node array stays in global memory; 1 every workgroup keeps a copy in LDS; 2 a copy with binary16
+                                     planes (32-byte nodes: a tree whose binary32 form does not fit and this one does -- the book-two cover) */
     size_t workspace_bytes;
     int swap_cap, waves_per_simd; /* entries per swap queue; waves per SIMD the kernel family is compiled for */
     int tile_order;               /* RT_TILE_ORDER_* */
