@@ -470,7 +470,12 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     // workgroup's share beside the stack, the box list and the smallest queues (rtl::rec_at<true>: Cornell box 138 -> 126 ms)
     const unsigned table = rt_lds_front_bytes((feat & ~1u) != 0u);
     const unsigned blob_bytes = (unsigned)s->flat.scene_blob.size();
-    const int reclds = list && swap && blob_bytes > 0u &&
+    // (a small TREE scene -- the host packed a blob for it, FlatScene::scene_blob -- takes that form when its node array fits as well:
+    // the lean general family and the one with sphere media / textures have kernels for it)
+    const char *no_rec = std::getenv("RT_NO_LDS_RECORDS"); // A/B
+    const char *no_lds_env = std::getenv("RT_NO_LDS_NODES");
+    const bool tree_form = !list && !wide && node_bytes > 0u && !(feat & (8u | 16u)) && (feat & 1u) != 0u && !(no_lds_env && *no_lds_env == '1');
+    const int reclds = (list || tree_form) && swap && blob_bytes > 0u && !(no_rec && *no_rec == '1') &&
                        rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, node_bytes, min_cap, table + rt_lds_scene_room(blob_bytes)).total <= lds_share;
     const unsigned front = table + (reclds ? rt_lds_scene_room(blob_bytes) : 0u);
     if (reclds) { // these five fields carry the arrays' byte offsets in the LDS instead of addresses
@@ -487,7 +492,8 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     const char *no_half = std::getenv("RT_NO_HALF_NODES");
     const char *want_half = std::getenv("RT_HALF_NODES"); // 1: the binary16 form wherever it exists, also when the binary32 nodes would fit (sweeps, A/B)
     const unsigned half_bytes = (unsigned)(s->flat.nodes_half.size() * sizeof(RtNodeH));
-    const bool half_possible = !list && !wide && swap && half_bytes > 0 && (feat & ~1u) != 0u && !(feat & (8u | 16u)) && !(no_lds && *no_lds == '1') &&
+    // (a small tree with its records in LDS keeps binary32 nodes there too: !reclds)
+    const bool half_possible = !list && !reclds && !wide && swap && half_bytes > 0 && (feat & ~1u) != 0u && !(feat & (8u | 16u)) && !(no_lds && *no_lds == '1') &&
                                !(no_half && *no_half == '1') && s->d_nodes_half &&
                                rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, half_bytes, min_cap, front).total <= lds_share;
     int ldsnodes = list || (!wide && node_bytes > 0 && !(no_lds && *no_lds == '1') && !(half_possible && want_half && *want_half == '1') &&

@@ -1140,7 +1140,13 @@ int flatten_scene(const SceneIR &ir, FlatScene *out, std::string *err) {
     }
     // the records the LIST kernels copy into LDS when they fit beside the stack and the queues (rt_api.cpp render_range decides per
     // launch), in the layout RtLaunch's offsets assume
-    if (fs.n_list > 0 && FlatScene::scene_blob_bytes(fs.xforms.size(), fs.prim_meta.size(), fs.materials.size()) <= (size_t)RT_LIST_SCENE_MAX) {
+    // ... and, since round 5, the kernels of a small TREE scene of the families that have that form (general prims, 16-bit references, no
+    // media over general boundaries: rt_kernels.hip part 4): what the Cornell box gained from it (+ 9.5 %, round 4) is there for any scene
+    // whose primitive tests read a transform level per chain level through the L1
+    const bool small_tree = fs.n_list == 0 && (fs.feature_mask & RT_FEAT_GENERAL) && !fs.wide && fs.n_leaf_prims <= RT_RECLDS_TREE_MAX &&
+                            !(fs.feature_mask & (RT_FEAT_MEDIUM_GENERAL | RT_FEAT_DEEP_CHAIN | RT_FEAT_MEDIUM_NESTED));
+    if ((fs.n_list > 0 || small_tree) &&
+        FlatScene::scene_blob_bytes(fs.xforms.size(), fs.prim_meta.size(), fs.materials.size(), fs.prim_geo.size()) <= (size_t)RT_LIST_SCENE_MAX) {
         auto put = [&](int k, const void *src, size_t bytes) {
             fs.scene_blob_off[k] = (uint32_t)fs.scene_blob.size();
             fs.scene_blob.resize(fs.scene_blob.size() + ((bytes + 15) & ~(size_t)15), 0);

@@ -87,13 +87,14 @@ struct FlatScene {
     bool wide = false;           // 32-bit references (more than 32767 prims or nodes)
     bool world_mid = true;       // every world-space sphere's centre and radius are <= 2^100 in magnitude (rtl::world_roots_rcp)
     int n_list = 0;              // > 0: `nodes` holds the box list of the n_list BVH leaves instead of the tree (small general scenes)
-    // list mode: the records the LIST kernels keep in LDS, packed {xforms, prim_geo, prim_meta, prim_extra, materials}, each array
+    // small general scenes (box list, or a tree of <= RT_RECLDS_TREE_MAX leaves): the records their kernels keep in LDS, packed {xforms, prim_geo, prim_meta, prim_extra, materials}, each array
     // at a 16-byte boundary; scene_blob_off[k] = byte offset of array k in the blob (RtLaunch::scene_blob)
     std::vector<unsigned char> scene_blob;
     uint32_t scene_blob_off[5] = {0, 0, 0, 0, 0};
-    static size_t scene_blob_bytes(size_t n_xforms, size_t n_prims, size_t n_materials) {
+    // (n_geo: prim_geo also holds the cube groups' records behind the prims)
+    static size_t scene_blob_bytes(size_t n_xforms, size_t n_prims, size_t n_materials, size_t n_geo) {
         auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
-        return up(n_xforms * sizeof(RtXform)) + up(n_prims * sizeof(RtPrimGeo)) + up(n_prims * sizeof(RtPrimMeta)) + up(n_prims * sizeof(RtPrimExtra)) +
+        return up(n_xforms * sizeof(RtXform)) + up(n_geo * sizeof(RtPrimGeo)) + up(n_prims * sizeof(RtPrimMeta)) + up(n_prims * sizeof(RtPrimExtra)) +
                up(n_materials * sizeof(RtMaterial));
     }
     int n_leaf_prims = 0;

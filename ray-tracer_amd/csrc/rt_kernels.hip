@@ -45,7 +45,8 @@
 #include "rt_lds.h"
 #include "rt_types.h"
 
-// The library is built from TWO compilations of this file (Makefile): part 1 holds the spheres-only and the lean general
+// The library is built from FOUR compilations of this file (Makefile; parts 3 and 4: the nested-media family, the small tree scenes with
+// their records in LDS): part 1 holds the spheres-only and the lean general
 // families plus the small kernels and every extern "C" entry; part 2 holds the families with media / textures, which sit
 // at their register limit and are compiled with the ordinary Vec3 division (-DRT_PLAIN_DIV3: the shared-reciprocal form of
 // rt_lane.h costs them 32-48 bytes of scratch per lane, +1 % on the book-two cover, where it gains 2 % elsewhere).
@@ -988,7 +989,12 @@ KernelFn pick3(bool lens, bool count, bool ldsnodes) {
 }
 // lds_mode: bit 0 = node array copied to LDS, bit 1 = swap-at-shade queues, bit 2 = 32-bit references (general families),
 // bit 3 = box list instead of the tree (general families, 16-bit references, always in LDS), bit 4 = (list + swap only) the scene's
-// records in LDS, bit 5 = (with bits 0 and 1; the family with sphere media / textures only) the LDS copy holds RtNodeH records
+// records in LDS, bit 5 = (with bits 0 and 1; the family with sphere media / textures only) the LDS copy holds RtNodeH records.
+// Bit 4 WITHOUT bit 3 (round 5): a small TREE scene with its records in LDS -- nodes in LDS too, swap queues, 16-bit references;
+// the lean general family (compilation 1) and the one with sphere media / textures (compilation 4) have that form
+#if RT_TU_PART == 0 || RT_TU_PART == 4
+KernelFn pick_reclds_tree(bool lens, bool count) { return pick3<true, 1, true, true, false, false, true>(lens, count, true); } // (the lean one: part 1)
+#endif
 #if RT_TU_PART == 0 || RT_TU_PART == 3
 // media inside the boundary of media (feature bit 16): MEDIUM = 3, the only family compiled with the nested evaluation (a real
 // call per inner medium, records in scratch memory: 6 x slower than MEDIUM = 2 on the same scene, so it is kept out of it).
@@ -1027,9 +1033,12 @@ extern "C" void *rt_pick_media_kernel(unsigned features, int lens, int count, in
 }
 #elif RT_TU_PART == 3
 extern "C" void *rt_pick_nested_kernel(int lens, int count, int lds_mode) { return (void *)pick_nested(lens != 0, count != 0, lds_mode); }
+#elif RT_TU_PART == 4
+extern "C" void *rt_pick_reclds_tree_kernel(int lens, int count) { return (void *)pick_reclds_tree(lens != 0, count != 0); }
 #elif RT_TU_PART == 1
 extern "C" void *rt_pick_media_kernel(unsigned features, int lens, int count, int lds_mode);
 extern "C" void *rt_pick_nested_kernel(int lens, int count, int lds_mode);
+extern "C" void *rt_pick_reclds_tree_kernel(int lens, int count);
 #endif
 #if RT_TU_PART == 0 || RT_TU_PART == 1
 namespace {
@@ -1040,6 +1049,14 @@ KernelFn pick(unsigned features, bool lens, bool count, int lds_mode) {
         return (KernelFn)rt_pick_nested_kernel(lens, count, lds_mode);
 #else
         return pick_nested(lens, count, lds_mode);
+#endif
+    }
+    if (!list && !wide && swap && ldsnodes && (lds_mode & 16) != 0 && !(features & 8u)) { // a small tree scene with its records in LDS
+        if ((features & ~1u) == 0u) return pick3<true, 0, false, true, false, false, true>(lens, count, true); // the lean family
+#if RT_TU_PART == 1
+        return (KernelFn)rt_pick_reclds_tree_kernel(lens, count);
+#else
+        return pick_reclds_tree(lens, count);
 #endif
     }
     if ((features & ~1u) != 0u) {

@@ -1196,7 +1196,7 @@ struct StackCubeGroups<S, decltype((void)S::kCubeGroups)> {
 };
 template <int GENERAL, int MEDIUM, class Stack>
 struct CubeGroups {
-    static constexpr bool value = GENERAL == 1 && MEDIUM <= 1 && StackCubeGroups<Stack>::value;
+    static constexpr bool value = GENERAL >= 1 && MEDIUM <= 1 && StackCubeGroups<Stack>::value; // (GENERAL == 2: the scene's records in LDS)
 };
 
 // one leaf step (tv.cur is a leaf reference): binary64 primitive test, then pop.
@@ -1212,9 +1212,9 @@ RT_HD void trav_leaf_step(const RtLaunch &L, V3 o, V3 d, SegCtx &sc, Trav &tv, S
     float tn_exit_x = 0.0f, tn_exit_y = 0.0f, tn_exit_z = 0.0f, tn_entry = 0.0f; // where the ray enters each candidate's box
     uint32_t faces = 0u; // three bits per candidate slot (0-2: entry face of x y z, 3-5: exit face): the face's prim is head + that
     if constexpr (CubeGroups<GENERAL, MEDIUM, Stack>::value) {
-        const RtPrimMeta &HM = rec_at(L.prim_meta, head);
+        const RtPrimMeta &HM = rec_at<GENERAL == 2>(L.prim_meta, head);
         if (HM.kind & RT_META_GROUP_BIT) {
-            const RtCubeGroup &C = reinterpret_cast<const RtCubeGroup &>(rec_at(L.prim_geo, HM.aux));
+            const RtCubeGroup &C = reinterpret_cast<const RtCubeGroup &>(rec_at<GENERAL == 2>(L.prim_geo, HM.aux));
             const bool sx = (f32_bits(tv.idx) >> 31) != 0u, sy = (f32_bits(tv.idy) >> 31) != 0u, sz = (f32_bits(tv.idz) >> 31) != 0u;
             // per axis: te the ray reaches the entry face's slab, ti leaves it; txi reaches the exit face's slab, tx leaves it
             const float te_x = fmaf(sx ? C.outer_hi[0] : C.outer_lo[0], tv.idx, tv.nx), ti_x = fmaf(sx ? C.inner_hi[0] : C.inner_lo[0], tv.idx, tv.fx);

@@ -12,7 +12,8 @@
 #define RT_MAX_HOISTED 4    /* scene-filling prims tested up front instead of through the BVH */
 #define RT_LIST_MAX 24      /* general scenes of up to this many BVH leaves are walked as a box LIST (rtl::trav_list_step) */
 #define RT_LIST_PRIM_BITS 6  /* bits of a LIST kernel's half-word stack entry that hold the leaf's prim index (rt_kernels.hip LdsStackList): a LIST scene has at most 1 << 6 leaf prims, hoisted ones included */
-#define RT_LIST_SCENE_MAX 12288 /* a LIST scene whose records (transforms, prims, materials) fit this many bytes AND the workgroup's LDS share keeps them in LDS */
+#define RT_LIST_SCENE_MAX 16384 /* a small general scene -- a LIST scene, or (round 5) a tree of at most RT_RECLDS_TREE_MAX leaves -- whose records (transforms, prims, materials) fit this many bytes AND the workgroup's LDS share keeps them in LDS */
+#define RT_RECLDS_TREE_MAX 64   /* leaf prims of a TREE scene that may keep its records in LDS (kernel families: general prims without media over general boundaries) */
 #ifndef RT_LIST_LDS_ARRAYS
 #define RT_LIST_LDS_ARRAYS 0x1F /* which of them are READ there: 1 xforms, 2 prim_geo, 4 prim_meta, 8 prim_extra, 16 materials (A/B knob) */
 #endif

@@ -363,7 +363,7 @@ extern "C" void lane_emul_lds_layout(unsigned stack_entries, unsigned block, uns
 
 // ---- which arithmetic this build carries, and its pieces one at a time ----
 // The records a box-LIST kernel copies into LDS (FlatScene::scene_blob, rtl::rec_at<true>): 0 when the blob holds every array byte
-// for byte at a 16-byte offset, -1 when the scene has none (not a list scene, or more than RT_LIST_SCENE_MAX bytes), else the
+// for byte at a 16-byte offset, -1 when the scene has none (neither a list scene nor a small tree, or more than RT_LIST_SCENE_MAX bytes), else the
 // number of the first array that is wrong.  *bytes_out = the blob's size.
 extern "C" int lane_emul_scene_blob_check(rt_scene *s, unsigned *bytes_out, int *n_list_out) {
     const rt::FlatScene &f = s->flat;
@@ -383,7 +383,8 @@ extern "C" int lane_emul_scene_blob_check(rt_scene *s, unsigned *bytes_out, int 
         end = off + arr[k].bytes;
     }
     if (f.scene_blob.size() % 16 != 0 || f.scene_blob.size() > (size_t)RT_LIST_SCENE_MAX) return 6;
-    if (f.prim_geo.size() != f.prim_meta.size() || f.prim_extra.size() != f.prim_meta.size()) return 7;
+    // (prim_geo also holds two slots per cube group behind the prims)
+    if (f.prim_geo.size() != f.prim_meta.size() + 2 * f.cube_groups.size() || f.prim_extra.size() != f.prim_meta.size()) return 7;
     return 0;
 }
 

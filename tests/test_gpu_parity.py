@@ -1000,30 +1000,84 @@ def test_a_shard_learns_its_tile_order_and_the_image_does_not_change(rt, scenes,
     sc.status()
 
 
+def _forty_leaves(scenes, textured):
+    """40 rotated rectangles and spheres on a floor, under a lamp (42 leaves, one transform level each: a TREE scene of 10 KB of records);
+    textured: one checker material, which puts the scene into the kernel family with textures"""
+    rng = np.random.default_rng(40)
+    d = scenes.SceneDesc(name="forty-leaves" + ("-textured" if textured else ""))
+    mats = [d.lambertian_rgb(rng.uniform(0.2, 0.9, 3)) for _ in range(4)] + [d.mat("metal", d.tex_solid((0.8, 0.8, 0.8)), 0.1)]
+    if textured:
+        d.textures.append(("checker", d.tex_solid((0.1, 0.1, 0.1)), d.tex_solid((0.9, 0.9, 0.9))))
+        mats.append(d.mat("lambertian", len(d.textures) - 1))
+    ex, ey = (1.0, 0.0, 0.0), (0.0, 1.0, 0.0)
+    d.sprite(d.geom("rectangle", 40.0, 40.0), mats[0], scenes.mat4_rotation(scenes.radians(-90.0), ex))
+    d.sprite(d.geom("rectangle", 12.0, 12.0), d.mat("diffuse_light", d.tex_solid((6.0, 6.0, 6.0))),
+             scenes.mat4_multiplied(scenes.mat4_translation((0.0, 14.0, 0.0)), scenes.mat4_rotation(scenes.radians(90.0), ex)))
+    for i in range(40):
+        at = (float(i % 8) * 3.0 - 10.5, 1.0 + 0.1 * (i % 5), float(i // 8) * 3.0 - 6.0)
+        M = scenes.mat4_multiplied(scenes.mat4_translation(at), scenes.mat4_rotation(float(rng.uniform(-1, 1)), ey))
+        if i % 3:
+            d.sprite(d.geom("sphere", float(rng.uniform(0.5, 1.0))), mats[int(rng.integers(len(mats)))], M)
+        else:
+            d.sprite(d.geom("rectangle", 2.0, 2.0), mats[int(rng.integers(len(mats)))], M)
+    d.camera = ((0.0, 9.0, -22.0), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0), 0.7, 1.0, 10.0, 0.0)
+    return d
+
+
 def test_small_general_scenes_with_their_records_in_lds(rt, scenes, oracle, gpu_device, monkeypatch):
-    """Box-LIST scenes (<= 24 leaves) whose transform / prim / material records fit keep them in the workgroup's LDS
-    (`rt_launch_config.records_in_lds`, rtl::rec_at<true>); the others -- too many records, or the kernels without the swap queues
-    -- read them from global memory as before.  Same arithmetic either way: every picture equals the oracle's bit for bit."""
+    """Small general scenes whose transform / prim / material records fit keep them in the workgroup's LDS
+    (`rt_launch_config.records_in_lds`, rtl::rec_at<true>): box-LIST scenes (<= 24 leaves) since round 4, TREE scenes of up to 64 leaves
+    since round 5 (a 40-leaf scene), in the lean general family and in the one with sphere media / textures; the others
+    -- too many records, or the kernels without the swap queues -- read them from global memory as before.  Same arithmetic either
+    way: every picture equals the oracle's bit for bit."""
     W, H, spp, depth = 96, 96, 8, 50
     seen = {}
     # (slab_stack: every camera ray crosses all 20 list boxes -- the list kernels' half-word stack at its deepest, 19 entries)
     for d in (scenes.cornell(), scenes.cube_row(2), scenes.cube_row(3), scenes.cube_row(3, levels=2), scenes.cube_row(3, levels=4), scenes.cube_row(5),
-              scenes.slab_stack(22)):
+              scenes.cube_row(9), scenes.slab_stack(22), _forty_leaves(scenes, False), _forty_leaves(scenes, True)):
         sc, cam = scenes.build_product(d, device=gpu_device)
         img = sc.render(cam, W, H, spp, depth, seed=3)
-        seen[d.name] = sc.last_launch_config()["records_in_lds"]
+        lc = sc.last_launch_config()
+        seen[d.name] = (lc["records_in_lds"], sc.info()["n_list"], lc["lds_nodes"])
         ref = oracle.build_oracle(d).render(W, H, spp, depth, seed=3, iterative=True, nthreads=8)
         assert np.array_equal(img, ref), d.name
         assert img.mean() > 0.01, d.name  # (lit: the comparison is not of two black pictures)
         sc.close()
-    assert seen["cornell-box"] == 1 and seen["cube-row-2x1"] == 1 and seen["slab-stack-22"] == 1, seen
-    assert seen["cube-row-3x4"] == 0 and seen["cube-row-5x1"] == 0, seen  # > 12 KiB of records; not a list scene
-    monkeypatch.setenv("RT_SWAP", "0")
-    d = scenes.cornell()
-    sc, cam = scenes.build_product(d, device=gpu_device)
-    img = sc.render(cam, W, H, spp, depth, seed=3)
-    assert sc.last_launch_config()["records_in_lds"] == 0
-    assert np.array_equal(img, oracle.build_oracle(d).render(W, H, spp, depth, seed=3, iterative=True, nthreads=8))
+    assert seen["cornell-box"][0] == 1 and seen["cube-row-2x1"][0] == 1 and seen["slab-stack-22"][0] == 1, seen
+    assert seen["cube-row-3x4"][0] == 0, seen  # 19 KB of records
+    # tree scenes: 32 leaves / 14 KB and 42 leaves / 10 KB keep their records (and their nodes) in LDS; 56 leaves / 25 KB do not
+    assert seen["cube-row-5x1"] == (1, 0, 1) and seen["forty-leaves"] == (1, 0, 1) and seen["forty-leaves-textured"] == (1, 0, 1), seen
+    assert seen["cube-row-9x1"][0] == 0 and seen["cube-row-9x1"][1] == 0, seen
+    for env in ("RT_SWAP", "RT_NO_LDS_RECORDS"):  # the kernels without the queues have no such form; the A/B switch
+        monkeypatch.setenv(env, "0" if env == "RT_SWAP" else "1")
+        for d in (scenes.cornell(), _forty_leaves(scenes, False)):
+            sc, cam = scenes.build_product(d, device=gpu_device)
+            img = sc.render(cam, W, H, spp, depth, seed=3)
+            assert sc.last_launch_config()["records_in_lds"] == 0
+            assert np.array_equal(img, oracle.build_oracle(d).render(W, H, spp, depth, seed=3, iterative=True, nthreads=8))
+        monkeypatch.delenv(env)
+
+
+@pytest.mark.parametrize("seed", [9100, 9101, 9104, 9105, 9108, 9112])
+def test_scenes_of_axis_aligned_cubes_on_the_gpu(rt, scenes, oracle, gpu_device, monkeypatch, seed):
+    """tests/test_random_scenes.py cubes_scene through the C ABI: cube groups (most of these scenes have dozens), glass cubes, fog; as
+    built, through the binary16 tree where the family has it (RT_HALF_NODES=1) and with a leaf per face (RT_NO_CUBE_GROUPS=1): the
+    oracle's image every time (the seeds are those without coinciding faces)."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from test_random_scenes import cubes_scene
+    d = cubes_scene(scenes, seed)
+    W, H, spp = 72, 56, 6
+    d.camera = d.camera[:4] + (W / H,) + d.camera[5:]
+    ref = oracle.build_oracle(d, bvh_seed=seed).render(W, H, spp, 40, seed=seed, iterative=True, nthreads=8)
+    for env in ({}, {"RT_HALF_NODES": "1"}, {"RT_NO_CUBE_GROUPS": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sc, cam = scenes.build_product(d, device=gpu_device)
+        assert np.array_equal(sc.render(cam, W, H, spp, 40, seed=seed), ref), (seed, env)
+        for k in env:
+            monkeypatch.delenv(k)
 
 
 def test_sweep_scene_78971_on_the_gpu(rt, scenes, oracle, gpu_device):

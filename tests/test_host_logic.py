@@ -481,18 +481,34 @@ def test_lds_layout_is_aligned_and_fits_for_every_launch_shape(lane_emul):
     assert l["cap"] % 2 == 0
 
 
-def test_scene_records_blob_of_list_scenes(scenes, lane_emul):
-    """Small general scenes (box-LIST walk, <= 24 leaves) carry their transform / prim / material records a second time as ONE
-    packed blob that the LIST kernels copy into LDS (rtl::rec_at<true>): every array byte for byte at a 16-byte offset, at most
-    RT_LIST_SCENE_MAX (12 KiB) in all.  A list scene with more records has no blob (its records stay in global memory), a scene
-    that is not walked as a list has none either."""
-    for d, want_list, want_blob in ((scenes.cornell(), 18, True), (scenes.cube_row(2), 14, True), (scenes.cube_row(3, levels=1), 20, True),
-                                    (scenes.cube_row(3, levels=4), 20, False), (scenes.cube_row(5), 0, False), (scenes.book_one(1, 1.5), 0, False)):
+def test_scene_records_blob_of_small_general_scenes(scenes, lane_emul):
+    """Small general scenes -- the box-LIST walk (<= 24 leaves) and, since round 5, trees of up to 64 leaves in the kernel families
+    that have the form -- carry their transform / prim / material records a second time as ONE packed blob that their kernels copy
+    into LDS (rtl::rec_at<true>): every array byte for byte at a 16-byte offset, at most RT_LIST_SCENE_MAX (16 KiB) in all.  A scene
+    with more records has no blob (its records stay in global memory); neither has a scene of more than 64 leaves, of spheres only,
+    or with media over general boundaries."""
+    cases = ((scenes.cornell(), 18, True), (scenes.cube_row(2), 14, True), (scenes.cube_row(3, levels=1), 20, True),
+             (scenes.cube_row(3, levels=4), 20, False),   # 20 leaves x 5 levels x 192 B: 19 KB
+             (scenes.cube_row(5), 0, True),               # 32 leaves: a TREE scene, 14 KB of records
+             (scenes.cube_row(9), 0, False),              # 56 leaves, 25 KB
+             (scenes.book_one(1, 1.5), 0, False), (scenes.cover(1, 1.0), 0, False), (scenes.instanced(), 0, False))
+    for d, want_list, want_blob in cases:
         sc, _ = scenes.build_product(d, device=-1)
         verdict, nbytes, n_list = lane_emul.scene_blob_check(sc)
         assert n_list == want_list, (d.name, n_list)
-        assert (verdict == 0 and 0 < nbytes <= 12288 and nbytes % 16 == 0) if want_blob else (verdict == -1 and nbytes == 0), (d.name, verdict, nbytes)
+        assert (verdict == 0 and 0 < nbytes <= 16384 and nbytes % 16 == 0) if want_blob else (verdict == -1 and nbytes == 0), (d.name, verdict, nbytes)
         sc.close()
+    # a tree scene with cube groups: the groups' records travel in the blob's prim_geo (two slots each behind the prims)
+    d = scenes.SceneDesc()
+    m = d.lambertian_rgb((0.7, 0.6, 0.5))
+    for i in range(5):
+        d.sprite(d.geom("cube", 1.0 + 0.1 * i, 1.0, 1.0), m, scenes.mat4_translation((2.0 * i - 4.0, 0.5, 0.0)))
+    d.sprite(d.geom("sphere", 100.0), d.mat("diffuse_light", d.tex_solid((0.7, 0.8, 1.0))), None)
+    d.camera = ((0.0, 3.0, -9.0), (0.0, 0.5, 0.0), (0.0, 1.0, 0.0), 0.8, 1.0, 10.0, 0.0)
+    sc, _ = scenes.build_product(d, device=-1)
+    assert sum(1 for q in range(sc.info()["n_prims"]) if sc.prim_group(q) == 6) == 5
+    verdict, nbytes, n_list = lane_emul.scene_blob_check(sc)
+    assert (verdict, n_list) == (0, 0) and nbytes > 0
 
 
 def test_the_deepest_stack_of_a_list_scene(scenes, oracle, lane_emul):
