@@ -246,7 +246,7 @@ def predicted_strong_scaling(n, ascending=False):
     return ({1: 1.0, 2: 1.96, 4: 3.81, 8: 7.12} if ascending else {1: 1.0, 2: 1.96, 4: 3.83, 8: 7.26}).get(n)
 
 
-PREDICTION_KERNELS = "0cfc6c472cf601d4"  # the kernel hash (rt_version) profiles/r05_shard_scaling*.log were measured with
+PREDICTION_KERNELS = "114bb391c73d10b8"  # the kernel hash (rt_version) profiles/r05_shard_scaling*.log were measured with
 
 
 def main():

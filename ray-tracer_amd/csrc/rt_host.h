@@ -148,12 +148,8 @@ inline uint16_t half_toward(float x, bool up) {
     }
     uint16_t h = (uint16_t)((sign << 15) | mag);
     const float back = to_float(h);
-    if (up ? back < x : back > x) { // one step further in the wanted direction
-        if ((up && !sign) || (!up && sign))
-            h = (uint16_t)(h + 1u); // away from zero
-        else
-            h = (uint16_t)(mag == 0u ? (up ? 0x0001u : 0x8001u) : h - 1u); // toward (and through) zero
-    }
+    // the truncation is on the wrong side exactly when the wanted direction points away from zero: one step further out
+    if (up ? back < x : back > x) h = (uint16_t)(h + 1u);
     return h;
 }
 

@@ -25,12 +25,15 @@
 //   random stream (include/rt_rng.h) and every sample is an independent value.
 //   The traversal stack lives in LDS, [depth][thread], conflict-free ds_read/write_b32.
 //   Six kernel families are instantiated from this one template (VGPRs / scratch bytes per lane / waves per SIMD of the timed
-//   builds, csrc/_obj/resource_usage.txt): spheres only (book-one: 120 / 0 / 4, 512-thread groups, two per CU); lean general
-//   -- matrices, rectangles, cubes, node geometries -- (Cornell box, walked as a box list with its transform / prim / material
-//   records in LDS and half-word stack entries: 128 / 64 / 4, 256-thread groups, four per CU); general + sphere media + textures (book-two cover: 128 / 64 / 4); media over general boundaries and chains of
-//   5-15 transform levels (168 / 352 / 3); media inside the boundary of media (168 / 2160 / 3, its own compilation); and each of
-//   the general ones with 32-bit node references (> 32 767 prims or nodes).  The scratch bytes of the first three belong to
-//   real calls on paths that hardly ever run (transcendentals, the reference's boxes for rays in an axis plane: rt_lane.h).
+//   builds, csrc/_obj/resource_usage.txt, tools/kernel_resources.py): spheres only (book-one: 120 / 0 / 4, 512-thread groups, two per
+//   CU); lean general -- matrices, rectangles, cubes, node geometries -- (Cornell box, walked as a box list with its transform / prim /
+//   material records in LDS and half-word stack entries: 128 / 64 / 4, 256-thread groups, four per CU; small TREE scenes keep their
+//   records in LDS too); general + sphere media + textures (book-two cover: 128 / 80 / 4, ONE 1024-thread group per CU since round 5,
+//   with a set of class queues per eight waves; the cover's tree -- 1406 nodes over cube groups, rtl::trav_leaf_step -- lives in LDS
+//   with binary16 planes, the HALF instantiation); media over general boundaries and chains of 5-15 transform levels (168 / 384 / 3);
+//   media inside the boundary of media (168 / 2160 / 3, its own compilation); and each of the general ones with 32-bit node references
+//   (> 32 767 prims or nodes).  The scratch bytes of the first three belong to real calls on paths that hardly ever run
+//   (transcendentals, the reference's boxes for rays in an axis plane: rt_lane.h).
 //
 // reduce_kernel -- pixel = (((s_0 + s_1) + s_2) + ...) / spp in sample order, the
 //   rounding of `pixel += color(...)` in examples/book-one.rs:69-76.  Per-sample
@@ -971,7 +974,8 @@ typedef void (*KernelFn)(const RtLaunch);
 
 template <bool GENERAL, int MEDIUM, bool TEXTURED, bool SWAP, bool WIDE = false, bool LIST = false, bool RECLDS = false, bool HALF = false>
 KernelFn pick3(bool lens, bool count, bool ldsnodes) {
-#define RT_PICK(LN, C, LD) return render_kernel<GENERAL, MEDIUM, TEXTURED, LN, C, (LD && !WIDE) || LIST || HALF, SWAP, WIDE, LIST, RECLDS, HALF>
+    // (LIST, HALF and a tree with RECLDS imply the node copy in LDS: one instantiation, not two)
+#define RT_PICK(LN, C, LD) return render_kernel<GENERAL, MEDIUM, TEXTURED, LN, C, (LD && !WIDE) || LIST || HALF || RECLDS, SWAP, WIDE, LIST, RECLDS, HALF>
     if (lens) {
         if (count) {
             if (ldsnodes) RT_PICK(true, true, true); else RT_PICK(true, true, false);

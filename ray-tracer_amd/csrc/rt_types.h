@@ -198,7 +198,7 @@ struct RtLaunch {
     const RtMaterial *materials;
     const RtTexture *textures;
     const uint8_t *image_blob;
-    // Box-LIST scenes whose records fit (lds_mode bit 4, kernels with RECLDS): the scene's records live in the workgroup's LDS.  prim_meta, prim_geo, prim_extra, xforms and
+    // Small general scenes whose records fit -- box-LIST scenes, trees of up to RT_RECLDS_TREE_MAX leaves -- (lds_mode bit 4, kernels with RECLDS): the scene's records live in the workgroup's LDS.  prim_meta, prim_geo, prim_extra, xforms and
     // materials above then hold the arrays' BYTE OFFSETS in the LDS instead of addresses (rtl::rec_at<true>), and the kernel
     // copies `scene_bytes` bytes from `scene_blob` -- the five arrays packed by the host in that layout -- to offset
     // `scene_lds_off` at entry.  `xforms_global` is the transform array in global memory in every mode: the per-level boxes in
