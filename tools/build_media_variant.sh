@@ -8,5 +8,5 @@ name=$1; defs=$2
 mkdir -p ../lib/variants _obj_$name
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-parameter --offload-arch=gfx950 -mllvm -simplifycfg-sink-common=false \
   $defs -DRT_TU_PART=2 -DRT_PLAIN_DIV3 -Rpass-analysis=kernel-resource-usage -c rt_kernels.hip -o _obj_$name/rt_kernels_media.o 2> _obj_$name/resource_usage.txt
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../lib/variants/librt_$name.so _obj/rt_host.o _obj/rt_api.o _obj/rt_kernels.o _obj_$name/rt_kernels_media.o _obj/rt_kernels_nested.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../lib/variants/librt_$name.so _obj/rt_host.o _obj/rt_api.o _obj/rt_kernels.o _obj_$name/rt_kernels_media.o _obj/rt_kernels_nested.o _obj/rt_kernels_reclds.o
 echo "built librt_$name.so ($defs)"
