@@ -262,6 +262,10 @@ typedef struct rt_launch_config {
     int records_in_lds;           /* 1: a small general scene (box-list walk) whose transform / prim / material records the kernel keeps in LDS */
 } rt_launch_config;
 int rt_last_launch_config(rt_scene *, rt_launch_config *out);
+/* What a render of this committed scene WOULD launch, decided by the same code a render runs, without a device: block_threads,
+ * lds_bytes, lds_nodes, swap, swap_cap, waves_per_simd, kernel_features, records_in_lds are filled (blocks_per_cu = the workgroups per
+ * CU the family's full occupancy asks for; the other fields 0).  Works on a scene committed with device = -1. */
+int rt_scene_plan_launch(const rt_scene *, rt_launch_config *out);
 /* A render of a SHARD (shard_count > 1) hands its tiles to the waves deepest first: the few 100-segment paths that finish a launch
  * alone (a fixed ~1 ms, 12 % of a 1/8 shard of book-one) then start early and the launch ends on shallow tiles.  The order is learnt:
  * the first render of a view (camera, size, shard, depth) adds up the path lengths per tile beside its sums and sorts the tiles (in eight

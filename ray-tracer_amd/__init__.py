@@ -134,6 +134,7 @@ ABI = {
     "rt_scene_workspace_bytes": (C.c_size_t, [_VP]),
     "rt_last_kernel_ms": (C.c_int, [_VP, C.POINTER(C.c_float)]),
     "rt_last_launch_config": (C.c_int, [_VP, C.POINTER(rt_launch_config)]),
+    "rt_scene_plan_launch": (C.c_int, [_VP, C.POINTER(rt_launch_config)]),
     "rt_scene_tile_order": (C.c_int, [_VP, _VP, _VP, C.c_int]),
     "rt_tonemap_rgb8": (None, [_DP, C.c_size_t, C.POINTER(C.c_uint8)]),
     "rt_write_ppm_p3": (C.c_int, [C.c_char_p, _DP, C.c_int, C.c_int]),
@@ -405,6 +406,12 @@ class Scene:
     def last_launch_config(self) -> dict:
         lc = rt_launch_config()
         _check(lib().rt_last_launch_config(self._h, C.byref(lc)))
+        return lc.as_dict()
+
+    def plan_launch(self) -> dict:
+        """what a render of this scene would launch (rt_scene_plan_launch): the same decision a render makes, without a device"""
+        lc = rt_launch_config()
+        _check(lib().rt_scene_plan_launch(self._h, C.byref(lc)))
         return lc.as_dict()
 
     def tile_order(self, capacity: int = 65536):

@@ -394,6 +394,74 @@ static uint64_t view_key(const rt_camera *cam, const rt_render_params *p) {
     return h | 1ull;
 }
 
+// What a render of this scene launches: the form of its kernel family, what lives in the workgroup's LDS, the launch's dynamic LDS.
+// Pure host logic (no HIP call): render_range uses it, rt_scene_plan_launch exposes it (tests on machines without a GPU).
+struct LaunchPlan {
+    unsigned block = 0, entry_bytes = 0, table = 0, front = 0, in_lds = 0, swap_cap = 0, lds_bytes = 0, groups_per_cu = 0;
+    int swap = 0, list = 0, wide = 0, reclds = 0, ldsnodes = 0, half = 0, lds_mode = 0;
+};
+static int plan_launch(const rt_scene *s, unsigned feat, int stack_entries_in, bool half_nodes_uploaded, LaunchPlan *out) {
+    LaunchPlan P;
+    const unsigned stack_entries = (unsigned)stack_entries_in;
+    // dynamic LDS (rt_lds.h: the one layout host and kernel share): the traversal stack, the waves' job state, a copy of the
+    // node array when the family's full occupancy still fits the CU's 160 KiB with it (book-one: 31 KB of nodes + 12 KB of
+    // stack), and the swap-at-shade queues with as many entries as are left (16 at least)
+    const unsigned block = P.block = (unsigned)rt_kernel_block_size(feat);
+    const int wide = P.wide = s->flat.wide ? 1 : 0;
+    const unsigned entry_bytes = P.entry_bytes = s->flat.n_list > 0 ? 2u : (wide ? 8u : 4u); // (rt_kernels.hip StackOf)
+    const unsigned node_bytes = (unsigned)(s->flat.nodes.size() * sizeof(RtNode));
+    const char *no_lds = std::getenv("RT_NO_LDS_NODES");
+    const bool lds_off = no_lds && *no_lds == '1';
+    // RT_SWAP=0 selects the kernels without the queues (A/B runs)
+    const char *swap_env = std::getenv("RT_SWAP");
+    const int swap = P.swap = !(swap_env && *swap_env == '0') || (feat & 16u) != 0u; // (the nested-media family exists with the queues only)
+    // keep the kernel family's full occupancy resident: that many workgroups per CU share its LDS
+    const unsigned groups_per_cu = P.groups_per_cu = std::max(1u, (unsigned)rt_kernel_waves_per_simd(feat) * 256u / block);
+    const unsigned lds_share = (RT_LDS_PER_CU / groups_per_cu) & ~(RT_LDS_GRANULE - 1u);
+    const int list = P.list = s->flat.n_list > 0; // the box list (< 1 KB) always lives in LDS
+    const unsigned min_cap = swap ? (block >= 512u ? (unsigned)RT_SWAP_CAP : 32u) : 0u; // the node copy must leave room for this
+    // the families with media / textures keep the log table at the front; a small general scene's records follow it when they fit the
+    // workgroup's share beside the stack, the box list or node array and the smallest queues (rtl::rec_at<true>: Cornell box 138 -> 126 ms)
+    const unsigned table = P.table = rt_lds_front_bytes((feat & ~1u) != 0u);
+    const unsigned blob_bytes = (unsigned)s->flat.scene_blob.size();
+    // (a small TREE scene -- the host packed a blob for it, FlatScene::scene_blob -- takes that form when its node array fits as well:
+    // the lean general family and the one with sphere media / textures have kernels for it)
+    const char *no_rec = std::getenv("RT_NO_LDS_RECORDS"); // A/B
+    const bool tree_form = !list && !wide && node_bytes > 0u && !(feat & (8u | 16u)) && (feat & 1u) != 0u && !lds_off;
+    const int reclds = P.reclds = (list || tree_form) && swap && blob_bytes > 0u && !(no_rec && *no_rec == '1') &&
+                                  rt_lds_layout(stack_entries, block, entry_bytes, node_bytes, min_cap, table + rt_lds_scene_room(blob_bytes)).total <= lds_share;
+    const unsigned front = P.front = table + (reclds ? rt_lds_scene_room(blob_bytes) : 0u);
+    const char *no_half = std::getenv("RT_NO_HALF_NODES");
+    const char *want_half = std::getenv("RT_HALF_NODES"); // 1: the binary16 form wherever it exists, also when the binary32 nodes would fit (sweeps, A/B)
+    const unsigned half_bytes = (unsigned)(s->flat.nodes_half.size() * sizeof(RtNodeH));
+    // the family with sphere media / textures has kernels for a tree with binary16 planes (RtNodeH, half the bytes); a small tree with its
+    // records in LDS keeps binary32 nodes there too (!reclds)
+    const bool family_has_half = (feat & ~1u) != 0u && !(feat & (8u | 16u));
+    const bool half_possible = !list && !reclds && !wide && swap && half_bytes > 0u && family_has_half && !lds_off && !(no_half && *no_half == '1') &&
+                               half_nodes_uploaded && rt_lds_layout(stack_entries, block, entry_bytes, half_bytes, min_cap, front).total <= lds_share;
+    int ldsnodes = list || (!wide && node_bytes > 0u && !lds_off && !(half_possible && want_half && *want_half == '1') &&
+                            rt_lds_layout(stack_entries, block, entry_bytes, node_bytes, min_cap, front).total <= lds_share);
+    // the binary32 nodes do not fit: the same tree with binary16 planes may (the book-two cover: 1406 nodes over cube groups, 45 KB beside
+    // a 56 KB stack).  RT_NO_HALF_NODES=1: never.
+    const int half = P.half = !ldsnodes && half_possible;
+    if (half) ldsnodes = 1;
+    if (reclds && !list && !ldsnodes) return fail(RT_ERR_DEVICE, "internal: a tree scene's records in LDS without its nodes");
+    if (half && !family_has_half) return fail(RT_ERR_DEVICE, "internal: binary16 nodes for a kernel family without that form");
+    P.ldsnodes = ldsnodes;
+    const unsigned in_lds = P.in_lds = ldsnodes ? (half ? half_bytes : node_bytes) : 0u;
+    unsigned swap_cap = swap ? rt_swap_cap_that_fits(stack_entries, block, entry_bytes, in_lds, groups_per_cu, front) : 0u;
+    if (const char *lim = std::getenv("RT_SWAP_CAP_LIMIT")) // A/B runs: fewer entries per class queue than would fit (families of 256 threads)
+        if (block < 512u && std::atoi(lim) >= 16) swap_cap = std::min(swap_cap, (unsigned)std::atoi(lim)) & ~1u;
+    P.swap_cap = swap_cap;
+    const RtLdsLayout lay = rt_lds_layout(stack_entries, block, entry_bytes, in_lds, swap ? rt_swap_cap_effective(block, swap_cap) : 0u, front);
+    if (!rt_lds_layout_aligned(lay)) return fail(RT_ERR_DEVICE, "internal: misaligned LDS layout");
+    P.lds_bytes = lay.total;
+    if (P.lds_bytes > RT_LDS_PER_CU) return fail(RT_ERR_UNSUPPORTED, "the scene's traversal stack does not fit a CU's LDS");
+    P.lds_mode = (ldsnodes ? 1 : 0) | (swap ? 2 : 0) | (wide ? 4 : 0) | (list ? 8 : 0) | (reclds ? 16 : 0) | (half ? 32 : 0);
+    *out = P;
+    return RT_OK;
+}
+
 // Render samples [s_begin, s_end) of every owned pixel.  accumulate: the tile buffer already holds the
 // raw sums of samples [0, s_begin) and is continued in sample order; finalize: divide by spp at the end.
 static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_params *p, int s_begin, int s_end, bool accumulate,
@@ -450,76 +518,32 @@ static int render_range(rt_scene *s, const rt_camera *cam, const rt_render_param
     const int lens = cam->lens_radius != 0.0;
     RtLaunch L;
     fill_launch(s, cam, p, n_owned, &L);
-    // dynamic LDS (rt_lds.h: the one layout host and kernel share): the traversal stack, the waves' job state, a copy of the
-    // node array when the family's full occupancy still fits the CU's 160 KiB with it (book-one: 31 KB of nodes + 12 KB of
-    // stack), and the swap-at-shade queues with as many entries as are left (16 at least)
-    const unsigned block = (unsigned)rt_kernel_block_size(feat);
-    const int wide = s->flat.wide ? 1 : 0;
-    const unsigned entry_bytes = s->flat.n_list > 0 ? 2u : (wide ? 8u : 4u); // (rt_kernels.hip StackOf)
-    const unsigned node_bytes = (unsigned)(s->flat.nodes.size() * sizeof(RtNode));
-    const char *no_lds = std::getenv("RT_NO_LDS_NODES");
-    // RT_SWAP=0 selects the kernels without the queues (A/B runs)
-    const char *swap_env = std::getenv("RT_SWAP");
-    const int swap = !(swap_env && *swap_env == '0') || (feat & 16u) != 0u; // (the nested-media family exists with the queues only)
-    // keep the kernel family's full occupancy resident: that many workgroups per CU share its LDS
-    const unsigned groups_per_cu = std::max(1u, (unsigned)rt_kernel_waves_per_simd(feat) * 256u / block);
-    const unsigned lds_share = (RT_LDS_PER_CU / groups_per_cu) & ~(RT_LDS_GRANULE - 1u);
-    const int list = s->flat.n_list > 0; // the box list (< 1 KB) always lives in LDS
-    const unsigned min_cap = swap ? (block >= 512u ? (unsigned)RT_SWAP_CAP : 32u) : 0u; // the node copy must leave room for this
-    // the families with media / textures keep the log table at the front; a LIST scene's records follow it when they fit the
-    // workgroup's share beside the stack, the box list and the smallest queues (rtl::rec_at<true>: Cornell box 138 -> 126 ms)
-    const unsigned table = rt_lds_front_bytes((feat & ~1u) != 0u);
-    const unsigned blob_bytes = (unsigned)s->flat.scene_blob.size();
-    // (a small TREE scene -- the host packed a blob for it, FlatScene::scene_blob -- takes that form when its node array fits as well:
-    // the lean general family and the one with sphere media / textures have kernels for it)
-    const char *no_rec = std::getenv("RT_NO_LDS_RECORDS"); // A/B
-    const char *no_lds_env = std::getenv("RT_NO_LDS_NODES");
-    const bool tree_form = !list && !wide && node_bytes > 0u && !(feat & (8u | 16u)) && (feat & 1u) != 0u && !(no_lds_env && *no_lds_env == '1');
-    const int reclds = (list || tree_form) && swap && blob_bytes > 0u && !(no_rec && *no_rec == '1') &&
-                       rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, node_bytes, min_cap, table + rt_lds_scene_room(blob_bytes)).total <= lds_share;
-    const unsigned front = table + (reclds ? rt_lds_scene_room(blob_bytes) : 0u);
+    // which form of the kernel family, what lives in LDS and how large the launch's dynamic LDS is: plan_launch (above), the ONE place
+    // that decides it -- rt_scene_plan_launch answers the same question without a device
+    LaunchPlan P;
+    if (int e = plan_launch(s, feat, L.stack_entries, s->d_nodes_half != nullptr, &P)) return e;
+    const unsigned block = P.block;
+    const int swap = P.swap, reclds = P.reclds, ldsnodes = P.ldsnodes, half = P.half;
+    const unsigned swap_cap = P.swap_cap, lds_bytes = P.lds_bytes;
     if (reclds) { // these five fields carry the arrays' byte offsets in the LDS instead of addresses
         const uint32_t *off = s->flat.scene_blob_off;
         L.scene_blob = (const unsigned char *)s->d_scene_blob;
-        L.scene_bytes = blob_bytes;
-        L.scene_lds_off = table;
-        if (RT_LIST_LDS_ARRAYS & 1) L.xforms = (const RtXform *)(uintptr_t)(table + off[0]);
-        if (RT_LIST_LDS_ARRAYS & 2) L.prim_geo = (const RtPrimGeo *)(uintptr_t)(table + off[1]);
-        if (RT_LIST_LDS_ARRAYS & 4) L.prim_meta = (const RtPrimMeta *)(uintptr_t)(table + off[2]);
-        if (RT_LIST_LDS_ARRAYS & 8) L.prim_extra = (const RtPrimExtra *)(uintptr_t)(table + off[3]);
-        if (RT_LIST_LDS_ARRAYS & 16) L.materials = (const RtMaterial *)(uintptr_t)(table + off[4]);
+        L.scene_bytes = (unsigned)s->flat.scene_blob.size();
+        L.scene_lds_off = P.table;
+        if (RT_LIST_LDS_ARRAYS & 1) L.xforms = (const RtXform *)(uintptr_t)(P.table + off[0]);
+        if (RT_LIST_LDS_ARRAYS & 2) L.prim_geo = (const RtPrimGeo *)(uintptr_t)(P.table + off[1]);
+        if (RT_LIST_LDS_ARRAYS & 4) L.prim_meta = (const RtPrimMeta *)(uintptr_t)(P.table + off[2]);
+        if (RT_LIST_LDS_ARRAYS & 8) L.prim_extra = (const RtPrimExtra *)(uintptr_t)(P.table + off[3]);
+        if (RT_LIST_LDS_ARRAYS & 16) L.materials = (const RtMaterial *)(uintptr_t)(P.table + off[4]);
     }
-    const char *no_half = std::getenv("RT_NO_HALF_NODES");
-    const char *want_half = std::getenv("RT_HALF_NODES"); // 1: the binary16 form wherever it exists, also when the binary32 nodes would fit (sweeps, A/B)
-    const unsigned half_bytes = (unsigned)(s->flat.nodes_half.size() * sizeof(RtNodeH));
-    // (a small tree with its records in LDS keeps binary32 nodes there too: !reclds)
-    const bool half_possible = !list && !reclds && !wide && swap && half_bytes > 0 && (feat & ~1u) != 0u && !(feat & (8u | 16u)) && !(no_lds && *no_lds == '1') &&
-                               !(no_half && *no_half == '1') && s->d_nodes_half &&
-                               rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, half_bytes, min_cap, front).total <= lds_share;
-    int ldsnodes = list || (!wide && node_bytes > 0 && !(no_lds && *no_lds == '1') && !(half_possible && want_half && *want_half == '1') &&
-                            rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, node_bytes, min_cap, front).total <= lds_share);
-    // the binary32 nodes do not fit: the same tree with binary16 planes (RtNodeH, half the bytes) may -- the family with sphere media /
-    // textures has kernels for it (the book-two cover: 1406 nodes over cube groups, 45 KB beside a 56 KB stack).  RT_NO_HALF_NODES=1: never.
-    const int half = !ldsnodes && half_possible;
-    if (half) {
-        ldsnodes = 1;
-        L.nodes = (const RtNode *)s->d_nodes_half; // RtNodeH records: the kernel's HALF instantiation reads them as such
-    }
-    const unsigned in_lds = ldsnodes ? (half ? half_bytes : node_bytes) : 0u;
-    unsigned swap_cap = swap ? rt_swap_cap_that_fits((unsigned)L.stack_entries, block, entry_bytes, in_lds, groups_per_cu, front) : 0u;
-    if (const char *lim = std::getenv("RT_SWAP_CAP_LIMIT")) // A/B runs: fewer entries per class queue than would fit (not for the 512-thread family: compiled in)
-        if (block < 512u && std::atoi(lim) >= 16) swap_cap = std::min(swap_cap, (unsigned)std::atoi(lim)) & ~1u;
+    if (half) L.nodes = (const RtNode *)s->d_nodes_half; // RtNodeH records: the kernel's HALF instantiation reads them as such
     L.swap_cap = (int)swap_cap;
-    const RtLdsLayout lay = rt_lds_layout((unsigned)L.stack_entries, block, entry_bytes, in_lds, swap ? rt_swap_cap_effective(block, swap_cap) : 0u, front);
-    if (!rt_lds_layout_aligned(lay)) return fail(RT_ERR_DEVICE, "internal: misaligned LDS layout");
-    const unsigned lds_bytes = lay.total;
-    if (lds_bytes > RT_LDS_PER_CU) return fail(RT_ERR_UNSUPPORTED, "the scene's traversal stack does not fit a CU's LDS");
     L.lds_bytes = lds_bytes;
 #if defined(RT_TEST_HOOKS) // librt_mi355x_testhooks.so only (Makefile): the shipped library reads no RT_TEST_* variable
     if (const char *t = std::getenv("RT_TEST_LDS_SHORT")) // claim fewer bytes than the layout needs -> the kernel must refuse
         if (*t == '1') L.lds_bytes = lds_bytes - 64u;
 #endif
-    const int lds_mode = (ldsnodes ? 1 : 0) | (swap ? 2 : 0) | (wide ? 4 : 0) | (list ? 8 : 0) | (reclds ? 16 : 0) | (half ? 32 : 0);
+    const int lds_mode = P.lds_mode;
     int per_cu = 0, n_cu = 0, rc = 0;
     const unsigned occ_key = feat | (lens ? 32u : 0u) | (count ? 64u : 0u) | ((unsigned)lds_mode << 7); // feat uses bits 0-4
     if (s->occ_key == occ_key && s->occ_lds == lds_bytes) {
@@ -1119,6 +1143,27 @@ int rt_scene_prim_bounds(const rt_scene *s, int prim, double out[6]) {
         out[i] = b.lo[i];
         out[3 + i] = b.hi[i];
     }
+    return RT_OK;
+}
+
+int rt_scene_plan_launch(const rt_scene *s, rt_launch_config *out) {
+    if (!s || !out) return fail(RT_ERR_INVALID, "null argument");
+    if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
+    const unsigned feat = kernel_features(s);
+    const int stack_entries = s->flat.n_list ? s->flat.n_list - 1 : std::min(RT_STACK_DEPTH, s->flat.max_depth + 1); // (fill_launch)
+    LaunchPlan P;
+    // (a scene committed without a device has not uploaded its binary16 tree: planned as if it had)
+    if (int e = plan_launch(s, feat, stack_entries, s->device < 0 ? !s->flat.nodes_half.empty() : s->d_nodes_half != nullptr, &P)) return e;
+    std::memset(out, 0, sizeof *out);
+    out->block_threads = (int)P.block;
+    out->lds_bytes = P.lds_bytes;
+    out->blocks_per_cu = (int)P.groups_per_cu; // what the family's full occupancy asks for (a render asks the runtime)
+    out->kernel_features = feat;
+    out->lds_nodes = P.ldsnodes ? (P.half ? 2 : 1) : 0;
+    out->swap = P.swap;
+    out->swap_cap = (int)P.swap_cap;
+    out->waves_per_simd = rt_kernel_waves_per_simd(feat);
+    out->records_in_lds = P.reclds;
     return RT_OK;
 }
 

@@ -228,6 +228,7 @@ extern "C" {
     pub fn rt_scene_workspace_bytes(s: *const rt_scene) -> usize;
     pub fn rt_last_kernel_ms(s: *mut rt_scene, ms: *mut c_float) -> c_int;
     pub fn rt_last_launch_config(s: *mut rt_scene, out: *mut rt_launch_config) -> c_int;
+    pub fn rt_scene_plan_launch(s: *const rt_scene, out: *mut rt_launch_config) -> c_int;
     pub fn rt_scene_tile_order(s: *mut rt_scene, order_out: *mut u32, cost_out: *mut u64, capacity: c_int) -> c_int;
 
     pub fn rt_tonemap_rgb8(rgb: *const c_double, n_pixels: usize, out_rgb8: *mut u8);

@@ -899,6 +899,19 @@ def test_library_and_torch_share_one_hip_runtime_in_either_order(rt, gpu_device,
             f.write(json.dumps(rec) + "\n")
 
 
+def test_a_render_launches_what_the_plan_says(rt, scenes, gpu_device):
+    """rt_scene_plan_launch (host logic, tested without a device in tests/test_host_logic.py) against what a render really launched
+    (rt_last_launch_config): the same workgroup size, dynamic LDS, node / record placement and queue capacity, for every kernel family;
+    blocks_per_cu: what the family's full occupancy asks for is what the runtime's occupancy query grants."""
+    for d in (scenes.book_one(1, 1.5), scenes.cornell(), scenes.cover(1, 1.0), scenes.cube_row(5), scenes.cube_row(9), scenes.instanced(), scenes.nested_media()):
+        sc, cam = scenes.build_product(d, device=gpu_device)
+        plan = sc.plan_launch()
+        sc.render(cam, 64, 48, 2, 10, seed=1)
+        real = sc.last_launch_config()
+        for k in ("block_threads", "lds_bytes", "lds_nodes", "swap", "swap_cap", "waves_per_simd", "kernel_features", "records_in_lds", "blocks_per_cu"):
+            assert plan[k] == real[k], (d.name, k, plan[k], real[k])
+
+
 def test_sample_workspace_limit_and_trim(rt, scenes, gpu_device):
     """the per-sample workspace (32 B per sample of a pass): sized to the render, limited per scene, given back by trim"""
     sc, cam = scenes.build_product(scenes.book_one(1, 1.5), device=gpu_device)

@@ -481,6 +481,67 @@ def test_lds_layout_is_aligned_and_fits_for_every_launch_shape(lane_emul):
     assert l["cap"] % 2 == 0
 
 
+def test_launch_plans_of_every_kernel_family(rt, scenes, monkeypatch):
+    """rt_scene_plan_launch: what a render WOULD launch -- workgroup size, dynamic LDS, where the node array and the records live, the
+    queues' capacity -- decided by the code a render runs (rt_api.cpp plan_launch), here without a device.  One scene per kernel
+    family and per form; the switches move the plan the way the README says.  (Round 5 found a plan that gave the spheres-only
+    family a binary16 tree it has no kernels for only on the GPU box, where the kernel refused the launch: this test is what
+    would have found it here.)"""
+    def plan(d):
+        sc, _ = scenes.build_product(d, device=-1)
+        return sc.plan_launch()
+    b = plan(scenes.book_one(1, 1.5))       # spheres only: two 512-thread groups per CU, each with its copy of the 484 nodes
+    assert (b["block_threads"], b["blocks_per_cu"], b["lds_nodes"], b["swap_cap"], b["records_in_lds"], b["kernel_features"]) == (512, 2, 1, 64, 0, 0)
+    assert b["lds_bytes"] == 79648 <= 80 * 1024  # stack + 484 nodes of 64 bytes + job state + three queues of 64
+    c = plan(scenes.cornell())               # lean general, box list: records + list in LDS, half-word stack entries
+    assert (c["block_threads"], c["blocks_per_cu"], c["lds_nodes"], c["records_in_lds"], c["swap_cap"], c["kernel_features"]) == (256, 4, 1, 1, 64, 1)
+    assert c["lds_bytes"] <= 40 * 1024
+    v = plan(scenes.cover(1, 1.0))           # sphere media + textures: one 1024-thread group, the tree with binary16 planes, two sets of queues
+    assert (v["block_threads"], v["blocks_per_cu"], v["lds_nodes"], v["records_in_lds"], v["swap_cap"], v["kernel_features"]) == (1024, 1, 2, 0, 64, 7)
+    depth = scenes.build_product(scenes.cover(1, 1.0), device=-1)[0].info()["max_depth"]
+    assert depth <= 15  # (round 4's tree of 3406 nodes: 16)
+    # the log table, the stack, 1406 nodes of 32 bytes, sixteen waves' job state, two sets of queues: one CU's LDS holds it
+    assert v["lds_bytes"] == 2048 + (depth + 1) * 4096 + 1406 * 32 + 16 * 32 + 2 * (32 + 3 * 124 * 64) <= 160 * 1024
+    t = plan(scenes.cube_row(5))             # lean general, a TREE of 32 leaves: records and nodes in LDS
+    assert (t["block_threads"], t["lds_nodes"], t["records_in_lds"]) == (256, 1, 1) and 32 <= t["swap_cap"] <= 64
+    t9 = plan(scenes.cube_row(9))            # 56 leaves, 25 KB of records: nodes in LDS, records in global memory
+    assert (t9["lds_nodes"], t9["records_in_lds"]) == (1, 0)
+    g = plan(scenes.instanced())             # media over general boundaries: three 256-thread groups, 3 waves per SIMD
+    assert (g["block_threads"], g["blocks_per_cu"], g["waves_per_simd"], g["records_in_lds"]) == (256, 3, 3, 0) and g["lds_nodes"] in (0, 1)
+    n = plan(scenes.nested_media())          # media inside media: its own family
+    assert n["kernel_features"] & 16 and n["lds_nodes"] in (0, 1) and n["swap"] == 1
+    # a field of 1300 spheres: node array + stack + queues no longer fit half a CU's LDS -> global memory; NEVER the binary16 form
+    # (only the family with sphere media / textures has kernels for it)
+    rng = np.random.default_rng(3)
+    d = scenes.SceneDesc()
+    m = d.lambertian_rgb((0.5, 0.5, 0.5))
+    for i in range(36):
+        for j in range(36):
+            d.sprite(d.geom("sphere", 0.3), m, scenes.mat4_translation((i - 18.0 + float(rng.uniform(0, 0.3)), 0.3, j - 18.0 + float(rng.uniform(0, 0.3)))))
+    d.sprite(d.geom("sphere", 3000.0), d.mat("diffuse_light", d.tex_solid((0.6, 0.7, 1.0))), None)
+    d.camera = ((20.0, 6.0, 8.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 0.5, 1.5, 20.0, 0.02)
+    big = plan(d)
+    assert (big["kernel_features"], big["lds_nodes"], big["block_threads"]) == (0, 0, 512)
+    monkeypatch.setenv("RT_HALF_NODES", "1")
+    assert plan(d)["lds_nodes"] == 0 and plan(scenes.book_one(1, 1.5))["lds_nodes"] == 1 and plan(scenes.cube_row(5))["lds_nodes"] == 1
+    monkeypatch.delenv("RT_HALF_NODES")
+    # the switches
+    for env, scene, field, want in (("RT_NO_HALF_NODES", scenes.cover(1, 1.0), "lds_nodes", 0), ("RT_NO_LDS_NODES", scenes.book_one(1, 1.5), "lds_nodes", 0),
+                                    ("RT_NO_LDS_RECORDS", scenes.cornell(), "records_in_lds", 0), ("RT_NO_LDS_RECORDS", scenes.cube_row(5), "records_in_lds", 0)):
+        monkeypatch.setenv(env, "1")
+        assert plan(scene)[field] == want, (env, field)
+        monkeypatch.delenv(env)
+    monkeypatch.setenv("RT_SWAP", "0")
+    w = plan(scenes.cover(1, 1.0))
+    assert (w["swap"], w["swap_cap"], w["lds_nodes"], w["records_in_lds"]) == (0, 0, 1, 0)  # without the queues' 47 KB the 90 KB of binary32 nodes fit
+    monkeypatch.delenv("RT_SWAP")
+    monkeypatch.setenv("RT_NO_CUBE_GROUPS", "1")
+    assert plan(scenes.cover(1, 1.0))["lds_nodes"] == 0  # 3406 nodes: 109 KB even with binary16 planes
+    monkeypatch.delenv("RT_NO_CUBE_GROUPS")
+    with pytest.raises(rt.RtError):
+        rt.Scene().plan_launch()  # not committed
+
+
 def test_scene_records_blob_of_small_general_scenes(scenes, lane_emul):
     """Small general scenes -- the box-LIST walk (<= 24 leaves) and, since round 5, trees of up to 64 leaves in the kernel families
     that have the form -- carry their transform / prim / material records a second time as ONE packed blob that their kernels copy

@@ -20,4 +20,11 @@ case "$1" in
 4) run 1100 10000 9900001 100 general X=1 ;;
 5) RANDOM_PARITY_SCALE=4 run 900 800 10000001 100 general X=1
    RANDOM_PARITY_SCALE=4 run 200 200 10100001 100 cubes RT_HALF_NODES=1 ;;
+# the long versions (fresh seeds again): evidence by weight
+6) run 1150 50000 11000001 40 general X=1 ;;
+7) run 1150 50000 11100001 40 general X=1 ;;
+8) run 600 10000 11200001 100 cover X=1
+   run 500 8000 11300001 100 book_one X=1 ;;
+9) run 550 15000 11400001 40 cubes X=1
+   run 550 15000 11500001 40 cubes RT_HALF_NODES=1 ;;
 esac
