@@ -21,7 +21,7 @@ pub trait Texture: Send + Sync + Debug {
 }
 
 fn texture_id(t: &Arc<dyn Texture>, recorder: &mut Recorder) -> Result<i32, Error> {
-    recorder.intern(t.as_ref(), "texture", |r| t.record(r))
+    recorder.intern(&**t, "texture", |r| t.record(r))
 }
 
 // ---------------------------------------------------------------- textures

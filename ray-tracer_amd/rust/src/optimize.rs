@@ -101,13 +101,16 @@ impl Drop for Committed {
     }
 }
 
-pub struct BoundingVolumeHierarchyNode<T> {
+pub struct BoundingVolumeHierarchyNode<T>
+where
+    T: Hit, // `dyn Bound<T>` is only well-formed for a `T` that can be hit
+{
     volume: T,
     objects: Vec<Arc<dyn Bound<T>>>,
     device: Mutex<Option<i32>>,            // where the world is to be committed (`on_device`); None: RT_MI355X_DEVICE, else 0
     committed: Mutex<Vec<Arc<Committed>>>, // the world on every device it has been rendered on so far
 }
-impl<T: Debug> Debug for BoundingVolumeHierarchyNode<T> {
+impl<T: Hit> Debug for BoundingVolumeHierarchyNode<T> {
     fn fmt(&self, f: &mut std::fmt::Formatter) -> std::fmt::Result {
         write!(f, "BoundingVolumeHierarchyNode {{ volume: {:?}, objects: {} }}", self.volume, self.objects.len())
     }

@@ -78,7 +78,7 @@ where
             None => -1, // never hit (src/sprite.rs:95,136)
         };
         let material = match &self.material {
-            Some(m) => recorder.intern(m.as_ref(), "material", |r| m.record(r))?,
+            Some(m) => recorder.intern(&**m, "material", |r| m.record(r))?,
             None => -1,
         };
         out.push(recorder.sprite(geometry, material, Some(self.transform.origin().as_slice()))?);
