@@ -26,10 +26,16 @@ def both(sc, cam, W, H, spp, depth, seed, tag):
     global n
     os.environ["RT_SWAP"] = "0"
     a, ca = sc.render(cam, W, H, spp, depth, seed=seed, counters=True)
+    la = sc.last_launch_config()["lds_nodes"]
     os.environ["RT_SWAP"] = "1"
     b, cb = sc.render(cam, W, H, spp, depth, seed=seed, counters=True)
+    lb = sc.last_launch_config()["lds_nodes"]
+    # (round 5: without the queues a tree may fit LDS with binary32 planes that with them only fits with binary16 ones -- another
+    # tree of culling boxes: the same image and segments; node steps, primitive tests and with them the keyed free-flight draws of a
+    # medium, one per medium TEST, follow the boxes)
+    same_tree = la == lb
     ok = np.array_equal(a, b) and cb["swap_parked"] == cb["swap_pulled"] and all(
-        ca[k] == cb[k] for k in ("samples", "segments", "nodes_visited", "prims_tested", "rng_draws"))
+        ca[k] == cb[k] for k in (("samples", "segments", "nodes_visited", "prims_tested", "rng_draws") if same_tree else ("samples", "segments")))
     n += 1
     if not ok:
         print("MISMATCH", tag, W, H, spp, depth, seed, "max diff", np.abs(a - b).max(), {k: (ca[k], cb[k]) for k in ca if ca[k] != cb[k]})
