@@ -243,7 +243,7 @@ def predicted_strong_scaling(n, ascending=False):
     """profiles/r05_shard_scaling*.log (tools/shard_scaling.py): speed-up over N = 1 predicted from per-shard times measured on ONE
     MI355X (1/N shard of the image, render + sums, before the gather), in the learnt tile order or in ascending order: a prediction
     printed beside the measurement, never instead of it"""
-    return ({1: 1.0, 2: 1.97, 4: 3.79, 8: 7.11} if ascending else {1: 1.0, 2: 1.97, 4: 3.86, 8: 7.26}).get(n)
+    return ({1: 1.0, 2: 1.96, 4: 3.80, 8: 7.09} if ascending else {1: 1.0, 2: 1.97, 4: 3.84, 8: 7.23}).get(n)
 
 
 PREDICTION_KERNELS = "114bb391c73d10b8"  # the kernel hash (rt_version) profiles/r05_shard_scaling*.log were measured with
