@@ -27,4 +27,10 @@ case "$1" in
    run 500 8000 11300001 100 book_one X=1 ;;
 9) run 550 15000 11400001 40 cubes X=1
    run 550 15000 11500001 40 cubes RT_HALF_NODES=1 ;;
+# more weight where the one explained pixel came from (scaled scenes), cameras, depth 100, four times the size
+10) run 600 40000 11600001 100 scaled X=1
+    run 450 20000 11700001 100 camera X=1 ;;
+11) run 1150 80000 11800001 100 general X=1 ;;
+12) RANDOM_PARITY_SCALE=4 run 650 10000 11900001 100 general X=1
+    RANDOM_PARITY_SCALE=4 run 450 2000 12000001 100 cubes RT_HALF_NODES=1 ;;
 esac
