@@ -33,4 +33,7 @@ case "$1" in
 11) run 1150 80000 11800001 100 general X=1 ;;
 12) RANDOM_PARITY_SCALE=4 run 650 10000 11900001 100 general X=1
     RANDOM_PARITY_SCALE=4 run 450 2000 12000001 100 cubes RT_HALF_NODES=1 ;;
+# the families with little weight so far: fields of 41 000 prims (32-bit references), and the cubes generator with a leaf per face
+13) run 700 600 12100001 100 wide X=1
+    run 300 6000 12200001 40 cubes RT_NO_CUBE_GROUPS=1 ;;
 esac
