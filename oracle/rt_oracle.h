@@ -37,7 +37,7 @@ typedef struct orc_scene orc_scene;
 orc_scene *orc_scene_new(void);
 void orc_scene_free(orc_scene *);
 
-/* cover.png probes only (tools/blue_hypotheses.py): earlier forms of ConstantMedium::hit / Dielectric / Isotropic that the
+/* cover.png probes only (tests/sweeps/blue_hypotheses.py): earlier forms of ConstantMedium::hit / Dielectric / Isotropic that the
  * reference's own comments hint at.  Compiled ONLY into the second, probe-only library oracle/_build/librt_oracle_hyp.so
  * (-DORC_WITH_HYPOTHESES): librt_oracle.so -- the parity anchor of every test and the timed CPU baseline -- is the plain
  * restatement and exports neither function (tests/test_oracle_kat.py checks).  The product has no counterpart. */

@@ -11,7 +11,7 @@
 // RTL_RCP64 is a reciprocal deliberately spoilt to v_rcp_f64's documented error bound).  Both have to match the oracle bit for bit.
 // The lane program's libm calls (log in media, sin in the checker texture, atan2 / acos in a sphere's uv) go through recording
 // wrappers -- the only place where the device's results may legitimately differ from the host's (its libm is not correctly
-// rounded, the host's mostly is): tools/libm_attribution.py replays a sample's recorded arguments through the device's functions
+// rounded, the host's mostly is): tests/sweeps/libm_attribution.py replays a sample's recorded arguments through the device's functions
 // (tools/microbench/libm_probe.hip) to show which call made a GPU pixel differ.  Macros, so that rt_lane.h stays as it is.
 #include <cmath>
 #include <cstdint>

@@ -7,7 +7,7 @@ import numpy as np
 import os
 
 ROOT = Path(__file__).resolve().parent.parent
-# ORC_LIB: the probe-only build with the ORC_HYP_* branches (tools/blue_hypotheses.py sets it); tests never do
+# ORC_LIB: the probe-only build with the ORC_HYP_* branches (tests/sweeps/blue_hypotheses.py sets it); tests never do
 LIB = C.CDLL(os.environ.get("ORC_LIB") or str(ROOT / "oracle" / "_build" / "librt_oracle.so"))
 
 _D, _DP, _VP, _I, _U64 = C.c_double, C.POINTER(C.c_double), C.c_void_p, C.c_int, C.c_uint64

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU box: the pixels of tools/random_parity.py's sweep that are not bit-identical to the oracle (profiles/r03_random_parity.json,
+"""GPU box: the pixels of tests/sweeps/random_parity.py's sweep that are not bit-identical to the oracle (profiles/r03_random_parity.json,
 `pixels_not_bit_identical`), looked at one by one: is the GPU's value the same from the timed build, the counting build and the
 build without swap queues (then it is arithmetic, not scheduling); which SAMPLE of the pixel differs (per-sample radiance through
 rt_render_progressive, one sample per pass, against the oracle's orc_render_pixel_samples) and by how much.
@@ -12,7 +12,7 @@ from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 from __graft_entry__ import load_package  # noqa: E402

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU box: WHY do the pixels listed in gpurun_out/diff_pixel_probe.json (tools/diff_pixel_probe.py) differ from the oracle?
+"""GPU box: WHY do the pixels listed in gpurun_out/diff_pixel_probe.json (tests/sweeps/diff_pixel_probe.py) differ from the oracle?
 (or the committed profiles/r03_experiments/diff_pixel_probe.json)  For the one sample of each pixel that differs, the host harness (tests/lane_emul.cpp, identical to the oracle on these scenes)
 records the arguments its path passed to log / sin / atan2 / acos; tools/microbench/libm_probe.hip evaluates the DEVICE's
 functions on the same arguments; the first call whose device result is not the host's bits is where the paths part (a 1-ulp
@@ -13,7 +13,7 @@ from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 from __graft_entry__ import load_package  # noqa: E402
@@ -46,7 +46,7 @@ def ulps(a, b):
 
 
 res = {"pixels": [], "random_arguments": {}}
-probe = OUT / "diff_pixel_probe.json"  # fresh from tools/diff_pixel_probe.py in the same call, else the committed copy
+probe = OUT / "diff_pixel_probe.json"  # fresh from tests/sweeps/diff_pixel_probe.py in the same call, else the committed copy
 if not probe.exists():
     probe = ROOT / "profiles" / "r03_experiments" / "diff_pixel_probe.json"
 for c in json.load(open(probe)):

@@ -144,7 +144,7 @@ def test_scenes_with_device_arithmetic_match_the_oracle(scenes, oracle, lane_dev
 
 
 def test_libm_calls_of_a_pixel_are_recorded(scenes, lane_emul):
-    """The hooks tools/libm_attribution.py stands on: the harness records the arguments its lane program passes to log / sin /
+    """The hooks tests/sweeps/libm_attribution.py stands on: the harness records the arguments its lane program passes to log / sin /
     atan2 / acos (the only functions whose device results may differ from the host's), and can move every log by an ulp to
     show how little of that reaches a picture."""
     sc, cam = scenes.build_product(scenes.cover(1, 1.0), device=-1)

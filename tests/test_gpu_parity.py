@@ -283,7 +283,7 @@ def test_full_size_cover_800x800x1000(rt, scenes, oracle, gpu_device):
 @pytest.mark.parametrize("name,W,H,spp,max_bad", [("book_one", 1200, 800, 8, 0), ("cornell", 600, 600, 8, 0), ("cover", 800, 800, 4, 0)])
 def test_whole_image_parity_at_baseline_sizes(rt, scenes, oracle, gpu_device, name, W, H, spp, max_bad):
     """every pixel of the BASELINE image sizes against the oracle (all host threads), at a sample count the CPU manages
-    in seconds (tools/full_parity.py does the same at 24-64 spp: profiles/r01_full_parity.json)"""
+    in seconds (tests/sweeps/full_parity.py does the same at 24-64 spp: profiles/r01_full_parity.json)"""
     import os
     desc = getattr(scenes, name)(*([1, W / H] if name != "cornell" else [W / H]))
     sc, cam = scenes.build_product(desc, device=gpu_device)

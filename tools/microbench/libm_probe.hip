@@ -1,6 +1,6 @@
 // libm_probe.hip -- the DEVICE's log / sin / atan2 / acos on given arguments (the four libm functions render_kernel calls:
 // rt_lane.h log_cold, checker_sine_cold, sphere_uv_cold), compiled like the kernels (-O3 -ffp-contract=off -fno-fast-math).
-// tools/libm_attribution.py feeds it the arguments a sample's path passed to those functions on the host and compares the
+// tests/sweeps/libm_attribution.py feeds it the arguments a sample's path passed to those functions on the host and compares the
 // results bit by bit: the device's libm is accurate to about an ulp, not correctly rounded.
 //   hipcc -O3 -ffp-contract=off -fno-fast-math --offload-arch=gfx950 libm_probe.hip -o libm_probe
 //   libm_probe in.bin out.bin      in: n x {fn, a, b} doubles (fn 0 log, 1 sin, 2 atan2(a, b), 3 acos), out: n doubles

@@ -1,11 +1,11 @@
 #!/bin/bash
-# GPU box, round 5: tools/random_parity.py over fresh seeds with the round's kernels (cube groups, the binary16 tree in LDS).
+# GPU box, round 5: tests/sweeps/random_parity.py over fresh seeds with the round's kernels (cube groups, the binary16 tree in LDS).
 #   tools/r05_sweeps.sh <part>     part 1: cover + cubes; part 2: general; part 3: book-one, cameras, scaled, wide, x4
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 run() { # timeout n first depth generator [env...]
   local t=$1 n=$2 first=$3 depth=$4 gen=$5; shift 5
-  env "$@" timeout -k 10 $t python3 tools/random_parity.py $n $first $depth $gen > gpurun_out/r05_sweep_${gen}_${first}.log 2>&1
+  env "$@" timeout -k 10 $t python3 tests/sweeps/random_parity.py $n $first $depth $gen > gpurun_out/r05_sweep_${gen}_${first}.log 2>&1
   tail -1 gpurun_out/r05_sweep_${gen}_${first}.log | cut -c1-420
 }
 case "$1" in
